@@ -1,0 +1,214 @@
+"""CPU tests: the oracle (oracle/oracle_np.py) against the golden vectors generated from the imported
+reference (oracle/gen_golden.py) and against the reference's own known-answer tests."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _eq(a, b):
+    """bit-exact incl. NaN positions"""
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.fixture(scope="module")
+def g1():
+    return np.load(os.path.join(GOLDEN, "G1_basis.npz"))
+
+
+def test_basis_bit_exact(g1):
+    dom = tuple(g1["dom"])
+    grid = g1["grid"]
+    for R in (1, 2, 5, 10, 32, 64):
+        for safe in (True, False):
+            g = grid if safe else g1["grid_nosafe"]
+            for kind, name in ((onp.LEGENDRE, "legendre"), (onp.MONOMIAL, "monomial")):
+                b = onp.Basis(kind, R, dom, safe_eval=safe)
+                assert _eq(onp.eval_all(b, g), g1[f"{name}_R{R}_safe{int(safe)}"]), (name, R, safe)
+    for R in (1, 2, 5, 6, 33):
+        b = onp.Basis(onp.FOURIER, R, dom)
+        assert _eq(onp.eval_all(b, grid), g1[f"fourier_R{R}_safe1"])
+
+
+def test_basis_log_ref_and_nd(g1):
+    ldom = tuple(g1["ldom"])
+    dom = tuple(g1["dom"])
+    for R in (5, 32):
+        assert _eq(onp.eval_all(onp.Basis(onp.LEGENDRE, R, ldom, log=True), g1["lgrid"]), g1[f"legendre_log_R{R}"])
+        assert _eq(onp.eval_all(onp.Basis(onp.MONOMIAL, R, ldom, log=True), g1["lgrid"]), g1[f"monomial_log_R{R}"])
+    assert _eq(onp.eval_all(onp.Basis(onp.LEGENDRE, 7, dom, ref_domain=(-0.5, 0.75)), g1["grid"]), g1["legendre_ref_R7"])
+    assert _eq(onp.eval_all(onp.Basis(onp.MONOMIAL, 7, dom, ref_domain=(-1.0, 2.0)), g1["grid"]), g1["monomial_ref_R7"])
+    assert _eq(onp.eval_all(onp.Basis(onp.LEGENDRE, 9, dom), g1["x3"]), g1["legendre_x3_R9"])
+    tb = onp.Basis(onp.LEGENDRE, 9, dom, matrix=g1["tm_matrix"])
+    assert _eq(onp.eval_all(tb, g1["x3"]), g1["transformed_x3"])
+    assert _eq(onp.eval_all(tb, g1["grid"], 4), g1["transformed_grid_size4"])
+
+
+def test_reference_known_answers(g1):
+    """test/test_moments.py:61-70 (Legendre closed forms), :44-58 (Fourier), :16-30 (Monomial)."""
+    v = np.array([0.0, 0.25, 0.5, 0.75, 1.0])
+    ref = np.array([np.ones_like(v), v, (3 * v ** 2 - 1.0) / 2.0, (5 * v ** 3 - 3 * v) / 2.0]).T
+    got = onp.eval_all(onp.Basis(onp.LEGENDRE, 4, (-1.0, 1.0)), v)
+    assert np.allclose(ref, got) and _eq(got, g1["kat_legendre"])
+    v_ = 2 * np.pi * v
+    ref = np.array([np.ones_like(v_), np.cos(v_), np.sin(v_), np.cos(2 * v_), np.sin(2 * v_), np.cos(3 * v_)]).T
+    got = onp.eval_all(onp.Basis(onp.FOURIER, 6, (0, 1)), v)
+    assert np.allclose(ref, got) and _eq(got, g1["kat_fourier"])
+    v2 = np.array([-2, -1, -0.5, 0, 0.5, 1, 2])
+    ref = np.array([v2 ** r for r in range(5)]).T
+    got = onp.eval_all(onp.Basis(onp.MONOMIAL, 5, (0, 1), safe_eval=False), v2)
+    assert np.allclose(ref, got) and _eq(got, g1["kat_monomial"])
+    # out-of-domain probes of SURVEY section 7: -1e-300 kept, 2.0000000000000004 dropped on domain (0, 2)
+    b = onp.Basis(onp.LEGENDRE, 3, (0.0, 2.0))
+    assert not np.isnan(onp.eval_all(b, np.array([-1e-300]))).any()
+    assert np.isnan(onp.eval_all(b, np.array([2.0000000000000004]))).all()
+
+
+def _level_chunks(N, steps, M, nan_every, seed=1234):
+    """Same synthetic data as oracle/gen_golden.py:_levels, as raw chunks x [M, n, 2|1]."""
+    out = []
+    for l in range(len(N)):
+        fine, coarse = onp.synth_level_samples(l, N[l], steps, seed=seed)
+        a = np.empty((N[l], 2, M))
+        for m in range(M):
+            a[:, 0, m] = fine + 0.125 * m
+            a[:, 1, m] = (coarse + 0.125 * m) if l > 0 else 0.0
+        if nan_every:
+            a[::nan_every, 0, 0] = np.nan
+            if l > 0:
+                a[3::nan_every * 2, 1, M - 1] = np.nan
+        x = a.transpose((2, 0, 1))
+        if l == 0:
+            x = x[:, :, :1]
+        out.append([x])
+    return out
+
+
+@pytest.fixture(scope="module")
+def g2():
+    return np.load(os.path.join(GOLDEN, "G2_estimate_mean.npz"))
+
+
+@pytest.mark.parametrize("tag", ["L3", "L5", "L3nan", "L3M4", "L1"])
+def test_estimate_mean_moments(g2, tag):
+    dom = tuple(g2["domain"])
+    N, steps, M, nan_every = g2[f"{tag}_N"], g2[f"{tag}_steps"], int(g2[f"{tag}_M"]), int(g2[f"{tag}_nan_every"])
+    chunks = _level_chunks(N, steps, M, nan_every)
+    for R in (5, 32, 64):
+        if M > 1 and R > 5:
+            continue
+        b = onp.Basis(onp.LEGENDRE, R, dom)
+        for bottom in (True, False):
+            r = onp.estimate_mean(chunks, lambda x: onp.moments_rows(b, x, bottom))
+            key = f"{tag}_leg{R}_b{int(bottom)}"
+            assert np.array_equal(r.n_samples, g2[key + "_n"])
+            assert np.array_equal(r.n_rm_samples, g2[key + "_n_rm"])
+            # same operations in the same order on the same machine class: bit-exact
+            assert _eq(r.l_means.reshape(g2[key + "_l_means"].shape), g2[key + "_l_means"])
+            assert _eq(r.l_vars.reshape(g2[key + "_l_vars"].shape), g2[key + "_l_vars"])
+            assert _eq(r.mean.reshape(g2[key + "_mean"].shape), g2[key + "_mean"])
+            assert _eq(r.var.reshape(g2[key + "_var"].shape), g2[key + "_var"])
+            if bottom and M == 1:
+                assert r.mean[0] == 1 and r.var[0] == 0          # test/test_run.py:106-107
+    if M == 1:
+        b = onp.Basis(onp.MONOMIAL, 6, dom)
+        r = onp.estimate_mean(chunks, lambda x: onp.moments_rows(b, x))
+        assert _eq(r.mean, g2[f"{tag}_mono6_mean"]) and _eq(r.var, g2[f"{tag}_mono6_var"])
+        r = onp.estimate_mean(chunks)
+        assert _eq(r.mean, g2[f"{tag}_plain_mean"].ravel()) and _eq(r.var, g2[f"{tag}_plain_var"].ravel())
+        assert np.array_equal(r.n_rm_samples, g2[f"{tag}_plain_n_rm"])
+        b8 = onp.Basis(onp.LEGENDRE, 8, dom)
+        r = onp.estimate_mean(chunks, lambda x: onp.eval_all(b8, x, 4)[..., 3])
+        assert _eq(r.mean, np.atleast_1d(g2[f"{tag}_moment3_mean"]).ravel())
+
+
+@pytest.mark.parametrize("tag", ["L3", "L3nan", "L1"])
+def test_estimate_mean_covariance(g2, tag):
+    g3 = np.load(os.path.join(GOLDEN, "G3_cov.npz"))
+    dom = tuple(g2["domain"])
+    N, steps, nan_every = g2[f"{tag}_N"], g2[f"{tag}_steps"], int(g2[f"{tag}_nan_every"])
+    chunks = _level_chunks(N, steps, 1, nan_every)
+    for R in (8, 16, 64):
+        key = f"{tag}_cov{R}"
+        Ncov = g3[key + "_Ncov"]
+        ch = [[c[0][:, :n, :]] for c, n in zip(chunks, Ncov)]
+        b = onp.Basis(onp.LEGENDRE, R, dom)
+        r = onp.estimate_mean(ch, lambda x: onp.covariance_rows(b, x))
+        assert np.array_equal(r.n_samples, g3[key + "_n"]) and np.array_equal(r.n_rm_samples, g3[key + "_n_rm"])
+        assert _eq(r.mean.reshape(R, R), g3[key + "_mean"])
+        assert _eq(r.var.reshape(R, R), g3[key + "_var"])
+        assert np.array_equal(r.mean.reshape(R, R)[:, 0], r.mean.reshape(R, R)[0, :])
+
+
+def test_regression_and_allocation():
+    with open(os.path.join(GOLDEN, "G4_alloc.json")) as f:
+        g4 = json.load(f)
+    for key, d in g4.items():
+        if not isinstance(d, dict):
+            continue
+        raw = np.array(d["raw_vars"])
+        L = raw.shape[0]
+        reg = onp.all_moments_variance_regression(raw, np.array(d["steps"]))
+        assert np.allclose(reg, np.array(d["reg_vars"]), rtol=1e-12, atol=0)
+        n_est = onp.estimate_n_samples_for_target_variance(1e-6, np.array(d["reg_vars"]), d["n_ops"], L)
+        assert np.array_equal(n_est, d["n_estimated"])
+        n_est = onp.estimate_n_samples_for_target_variance(1e-5, raw, d["n_ops"], L)
+        assert np.array_equal(n_est, d["n_estimated_raw"])
+    assert np.allclose(onp.determine_level_parameters(5, [0.5, 0.01]), g4["level_params_5"], rtol=0, atol=0)
+    assert onp.determine_level_parameters(1, [0.5, 0.01]) == g4["level_params_1"]
+
+
+def test_reference_golden_chain():
+    """test/test_sampling_pools.py:18,85-87: Legendre(5) means of 3 levels x 10 md5-seeded synthetic samples."""
+    with open(os.path.join(GOLDEN, "G7_chain.json")) as f:
+        g7 = json.load(f)
+    chunks = []
+    for l, lev in enumerate(g7["levels"]):
+        fine = np.array(lev["fine"])[:, 0]
+        coarse = np.array(lev["coarse"])[:, 0]
+        x = np.stack([fine, coarse], axis=-1)[None]
+        chunks.append([x[:, :, :1] if l == 0 else x])
+    b = onp.Basis(onp.LEGENDRE, 5, tuple(g7["domain"]))
+    r = onp.estimate_mean(chunks, lambda x: onp.moments_rows(b, x))
+    assert r.mean[0] == 1 and r.var[0] == 0
+    assert np.allclose(g7["ref_means_test_sampling_pools_py_18"], r.mean, atol=1e-5)
+    assert np.array_equal(r.mean, np.array(g7["means"])) and np.array_equal(r.var, np.array(g7["vars"]))
+
+
+def test_orthogonal_moments():
+    g5 = np.load(os.path.join(GOLDEN, "G5_ortho.npz"))
+    for name in ("norm12", "norm110", "lognorm"):
+        for R in (7, 21, 41):
+            key = f"{name}_R{R}"
+            cov = g5[key + "_cov"]
+            for tol in (1e-4, 0.0, 1e-10):
+                tk = key + "_tol{:g}".format(tol)
+                L, ev, thr = onp.construct_orthogonal_matrix(cov, tol)
+                assert thr == int(g5[tk + "_threshold"])
+                assert np.allclose(ev, g5[tk + "_eval"], rtol=1e-9, atol=1e-13)
+                assert np.allclose(L, g5[tk + "_L"], rtol=1e-7, atol=1e-9)
+            # test/test_distribution.py:180: ||L cov L^T - I|| < 1e-10 for the kept directions
+            L, ev, thr = onp.construct_orthogonal_matrix(cov, 1e-4)
+            assert np.linalg.norm(L @ cov @ L.T - np.eye(L.shape[0])) < 1e-8
+
+
+@pytest.mark.parametrize("key", ["norm12_R7", "norm12_R21", "norm110_R21", "lognorm_R21"])
+def test_maxent_oracle(key):
+    g6 = np.load(os.path.join(GOLDEN, "G6_maxent.npz"))
+    R = int(key.split("_R")[1])
+    dom = tuple(g6[key + "_domain"])
+    b = onp.Basis(onp.LEGENDRE, R, dom, matrix=g6[key + "_L"])
+    o = onp.MaxEntOracle(b, g6[key + "_moment_data"], dom)
+    res = o.solve(tol=1e-8)
+    assert res.success
+    # QUADPACK sub-interval layout and trust-region iterates are not pinned by any reference test
+    # (SURVEY 8(c)); the converged multipliers are: both solve the same strictly convex problem.
+    assert np.allclose(o.multipliers, g6[key + "_sd_multipliers"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(o.density(g6[key + "_xgrid"]), g6[key + "_sd_density"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(o.cdf(g6[key + "_xgrid"][::8]), g6[key + "_sd_cdf"], rtol=1e-6, atol=1e-8)
