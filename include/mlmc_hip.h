@@ -1,0 +1,137 @@
+/*
+ * mlmc_hip.h -- C ABI of libmlmc_hip.so: MI355X (gfx950) moment estimation and maximum-entropy
+ * PDF reconstruction for multilevel Monte Carlo.
+ *
+ * The reference (GeoMop/MLMC, /root/reference) is pure Python and has no FFI of its own; the
+ * boundary it offers for this path is a set of Python call signatures.
+ * Each entry point below names the reference interface it replaces (file:line relative to
+ * /root/reference).  Host code (the mlmc_amd Python package) binds these with ctypes; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success, non-zero on error (message through
+ * mlmc_last_error(), thread-local).  The caller owns every buffer passed in; the library owns
+ * its device scratch.  `mem_kind` says where a caller buffer lives (host or the bound device).
+ * One process binds one device (one process per GPU); handles are not thread-safe.
+ * All floating point is IEEE fp64, all counts int64.  No CPU fallback exists: without a HIP
+ * device every compute entry point fails.
+ */
+#ifndef MLMC_HIP_H
+#define MLMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLMC_ABI_VERSION 1
+
+/* basis kinds -- mlmc/moments.py: Legendre :174-229, Monomial :111-130, Fourier :133-171;
+ * IDENTITY = the quantity itself (estimate_mean of a plain quantity, quantity_estimate.py:22-80) */
+enum { MLMC_LEGENDRE = 0, MLMC_MONOMIAL = 1, MLMC_FOURIER = 2, MLMC_IDENTITY = 3 };
+/* accumulation modes */
+enum {
+    MLMC_MODE_MOMENTS = 0,  /* qe.moments + estimate_mean    (quantity_estimate.py:96-119, :22-80)  K = R      */
+    MLMC_MODE_COV = 1       /* qe.covariance + estimate_mean (quantity_estimate.py:122-156, :22-80) K = R * R  */
+};
+enum { MLMC_HOST = 0, MLMC_DEVICE = 1 };
+
+typedef struct mlmc_basis mlmc_basis;
+typedef struct mlmc_accum mlmc_accum;
+
+/* Plain-data image of a reference Moments object (mlmc/moments.py:10-39):
+ * t = (x - shift) * scale + ref0 (after log(x) if is_log); values with t outside [ref0, ref1]
+ * are NaN-masked when is_clip (Moments.clip, moments.py:58-67).  `matrix` (row-major
+ * [out_size][size], host pointer, may be NULL) is TransformedMoments._transform (moments.py:232-259). */
+typedef struct {
+    int32_t kind;
+    int32_t size;       /* number of basis functions R of the underlying family */
+    double shift;       /* Moments._linear_shift */
+    double scale;       /* Moments._linear_scale */
+    double ref0, ref1;  /* Moments.ref_domain */
+    int32_t is_log;     /* Moments._is_log */
+    int32_t is_clip;    /* Moments._is_clip (safe_eval) */
+    int32_t out_size;   /* rows of `matrix`; 0 = no linear transform */
+    int32_t reserved;
+    const double *matrix;
+} mlmc_basis_desc;
+
+/* ---- runtime -------------------------------------------------------------------------- */
+/* Bind this process to HIP device `device` (>= 0). flags: bit0 = record HIP-event timing of the
+ * accumulation kernels (read back with mlmc_accum_kernel_time). */
+int mlmc_init(int device, int flags);
+void mlmc_shutdown(void);
+const char *mlmc_last_error(void);
+int mlmc_abi_version(void);
+/* name[<=256], CU count, wavefront size, total HBM bytes of the bound device */
+int mlmc_device_info(char *name, int name_len, int *n_cu, int *wave_size, int64_t *hbm_bytes);
+
+/* ---- moment functions ----------------------------------------------------------------- */
+int mlmc_basis_create(const mlmc_basis_desc *desc, mlmc_basis **out);
+void mlmc_basis_destroy(mlmc_basis *b);
+/* Moments.eval_all(value, size) (moments.py:90-93; legvander/polyvander/Fourier/TransformedMoments
+ * ._eval_all :122-126,:145-162,:195-197,:256-259): out[i * size + r] for i < n, r < size.
+ * Masked values give NaN in every column, as in the reference. */
+int mlmc_basis_eval(const mlmc_basis *b, const double *x, int64_t n, int32_t size, double *out, int mem_kind);
+
+/* ---- level-difference accumulation (the hot loop) ------------------------------------- */
+/* One accumulator = one estimate_mean() call (quantity_estimate.py:22-80) over `n_levels` levels of a
+ * quantity with `n_comp` (= M) scalar components; rows K = n_comp * R (MOMENTS) or n_comp * R * R (COV),
+ * row index m * R + r / m * R * R + i * R + j (mom_at_bottom / cov_at_bottom = True layout). */
+int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32_t n_comp, mlmc_accum **out);
+void mlmc_accum_destroy(mlmc_accum *a);
+int mlmc_accum_reset(mlmc_accum *a);
+/* One chunk of level `level`: fine[m * n + k], coarse[m * n + k] (coarse == NULL at level 0:
+ * SampleStorage.sample_pairs_level returns [M, n, 1] there, sample_storage.py:261-285).
+ * Replaces eval_moments/eval_cov + mask_nan_samples + the two np.sum of quantity_estimate.py:43-65.
+ * Asynchronous on the library's stream; host buffers are staged before the call returns. */
+int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const double *coarse, int64_t n, int mem_kind);
+/* Writes per level l: n[l] (kept samples), n_rm[l] (NaN-masked samples), s[l * K + k] = sum of
+ * level differences, sp[l * K + k] = sum of squared differences (quantity_estimate.py:46-47,64-65).
+ * Outputs in host or device memory (device: for an RCCL all-reduce over ranks before the host reads them).
+ * Synchronises the stream; idempotent. */
+int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, double *sp, int mem_kind);
+/* HIP-event time (ms) and launch count of the dominant accumulation kernel since create/reset
+ * (needs mlmc_init flag bit0); also the algorithmic HBM bytes those launches had to read. */
+int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes);
+
+/* ---- maximum-entropy density (mlmc/tool/simple_distribution.py:9-327) ------------------ */
+typedef struct {
+    double tol;          /* gradient-norm tolerance (estimate_density_minimize tol, :50) */
+    int32_t max_it;      /* Newton iterations (reference: trust-ncg maxiter 20, :60) */
+    int32_t n_intervals; /* composite Gauss-Legendre sub-intervals on [a, b] (0 = default 64) */
+    int32_t gauss_degree;/* points per sub-interval (reference uses 21, :45); 0 = 21 */
+    int32_t reserved;
+    double stab_penalty; /* Distribution._stab_penalty (distribution.py:236); 0 for SimpleDistribution */
+    double penalty_coef; /* end-point decay penalty coefficient (distribution.py:47 = 10; simple: 0) */
+    int32_t decay_left, decay_right; /* force_decay flags */
+} mlmc_maxent_opts;
+
+typedef struct {
+    int32_t nit;
+    int32_t success;
+    double fun;        /* final functional value */
+    double grad_norm;  /* ||gradient||_2 at the solution (result.fun_norm, :93) */
+    double moment0;    /* integral of the density before the normalisation fix (:81-86) */
+    int32_t n_quad;
+    int32_t reserved;
+} mlmc_maxent_info;
+
+/* Minimise F(l) = sum_i mu_i l_i / sigma_i + int exp(-phi(x).l/sigma) dx (simple_distribution.py:259-327)
+ * starting from lambda_io (size R1 = number of moments used, <= basis out size); on return lambda_io holds
+ * the multipliers (normalisation fix of :86 NOT applied; see moment0), hess_out (may be NULL) the final
+ * Hessian [R1 * R1].  prev_lambda/n_prev: Distribution's stabilisation term (distribution.py:358-359), may be NULL/0. */
+int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma, int32_t R1, double a, double bnd_b,
+                      const mlmc_maxent_opts *opts, const double *prev_lambda, int32_t n_prev, double *lambda_io,
+                      double *hess_out, mlmc_maxent_info *info);
+/* SimpleDistribution.density (:96-105): out[i] = exp(clip(-phi(x_i).lambda/sigma, -200, 200)) */
+int mlmc_density_eval(const mlmc_basis *b, const double *lambda, const double *sigma, int32_t R1, const double *x,
+                      int64_t n, double *out, int mem_kind);
+/* integral of the density over [lo_i, hi_i] by `degree`-point Gauss-Legendre per interval (cdf :108-125) */
+int mlmc_density_integrate(const mlmc_basis *b, const double *lambda, const double *sigma, int32_t R1, const double *lo,
+                           const double *hi, int64_t n, int32_t degree, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLMC_HIP_H */

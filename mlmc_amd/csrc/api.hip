@@ -1,0 +1,356 @@
+// C-ABI entry points of libmlmc_hip.so (include/mlmc_hip.h): runtime, basis objects, accumulators.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "common.hpp"
+
+namespace mlmc {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(const std::string &msg) {
+    g_err = msg;
+    return 1;
+}
+Runtime &rt() {
+    static Runtime r;
+    return r;
+}
+
+int ensure(void **p, size_t *cap, size_t bytes) {
+    if (bytes <= *cap && *p) return 0;
+    if (*p) {
+        // earlier launches on the stream may still use the old buffer
+        MLMC_HIP_CHECK(hipStreamSynchronize(rt().stream));
+        MLMC_HIP_CHECK(hipFree(*p));
+        *p = nullptr;
+        *cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    MLMC_HIP_CHECK(hipMalloc(p, want));
+    *cap = want;
+    return 0;
+}
+
+int timing_begin(mlmc_accum *a) {
+    if (!(rt().flags & 1)) return 0;
+    if (a->ev_used + 2 > a->ev.size()) {
+        hipEvent_t e0, e1;
+        MLMC_HIP_CHECK(hipEventCreate(&e0));
+        MLMC_HIP_CHECK(hipEventCreate(&e1));
+        a->ev.push_back(e0);
+        a->ev.push_back(e1);
+    }
+    MLMC_HIP_CHECK(hipEventRecord(a->ev[a->ev_used], rt().stream));
+    return 0;
+}
+int timing_end(mlmc_accum *a) {
+    if (!(rt().flags & 1)) return 0;
+    MLMC_HIP_CHECK(hipEventRecord(a->ev[a->ev_used + 1], rt().stream));
+    a->ev_used += 2;
+    return 0;
+}
+static int timing_collect(mlmc_accum *a) {
+    for (size_t i = 0; i + 1 < a->ev_used; i += 2) {
+        float ms = 0.f;
+        MLMC_HIP_CHECK(hipEventElapsedTime(&ms, a->ev[i], a->ev[i + 1]));
+        a->ms_total += ms;
+    }
+    a->ev_used = 0;
+    return 0;
+}
+
+static int need_runtime() {
+    if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
+    return 0;
+}
+
+}  // namespace mlmc
+
+using namespace mlmc;
+
+extern "C" {
+
+int mlmc_abi_version(void) { return MLMC_ABI_VERSION; }
+const char *mlmc_last_error(void) { return g_err.c_str(); }
+
+int mlmc_init(int device, int flags) {
+    Runtime &r = rt();
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail("no HIP device available: libmlmc_hip has no CPU fallback");
+    if (device < 0 || device >= count) return fail("mlmc_init: device index out of range");
+    if (r.ready && r.device == device) {
+        r.flags = flags;
+        return 0;
+    }
+    if (r.ready) return fail("mlmc_init: this process is already bound to another device (one process per GPU)");
+    MLMC_HIP_CHECK(hipSetDevice(device));
+    MLMC_HIP_CHECK(hipGetDeviceProperties(&r.prop, device));
+    if (std::strncmp(r.prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(std::string("mlmc_init: kernels are built for gfx950 only, device is ") + r.prop.gcnArchName);
+    MLMC_HIP_CHECK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    r.device = device;
+    r.flags = flags;
+    r.n_cu = r.prop.multiProcessorCount;
+    r.ready = true;
+    return 0;
+}
+
+void mlmc_shutdown(void) {
+    Runtime &r = rt();
+    if (!r.ready) return;
+    (void)hipStreamSynchronize(r.stream);
+    (void)hipStreamDestroy(r.stream);
+    r.stream = nullptr;
+    r.ready = false;
+    r.device = -1;
+}
+
+int mlmc_device_info(char *name, int name_len, int *n_cu, int *wave_size, int64_t *hbm_bytes) {
+    if (need_runtime()) return 1;
+    if (name && name_len > 0) {
+        std::strncpy(name, rt().prop.name, (size_t)name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (n_cu) *n_cu = rt().prop.multiProcessorCount;
+    if (wave_size) *wave_size = rt().prop.warpSize;
+    if (hbm_bytes) *hbm_bytes = (int64_t)rt().prop.totalGlobalMem;
+    return 0;
+}
+
+// ---- basis ---------------------------------------------------------------------------------
+int mlmc_basis_create(const mlmc_basis_desc *d, mlmc_basis **out) {
+    if (need_runtime()) return 1;
+    if (!d || !out) return fail("mlmc_basis_create: null argument");
+    if (d->size <= 0) return fail("mlmc_basis_create: size must be > 0");   // moments.py:11 assert size > 0
+    if (d->kind < MLMC_LEGENDRE || d->kind > MLMC_IDENTITY) return fail("mlmc_basis_create: unknown kind");
+    if (d->kind == MLMC_IDENTITY && d->size != 1) return fail("mlmc_basis_create: IDENTITY has size 1");
+    if (d->out_size < 0 || (d->out_size > 0 && !d->matrix)) return fail("mlmc_basis_create: matrix missing");
+    mlmc_basis *b = new (std::nothrow) mlmc_basis();
+    if (!b) return fail("out of memory");
+    b->p.kind = d->kind;
+    b->p.size = d->size;
+    b->p.shift = d->shift;
+    b->p.scale = d->scale;
+    b->p.ref0 = d->ref0;
+    b->p.ref1 = d->ref1;
+    b->p.is_log = d->is_log;
+    b->p.is_clip = d->is_clip;
+    b->out_size = d->out_size;
+    const int R = d->size;
+    std::vector<double> coef(R, 0.0);
+    b->scale_c.assign(R, 1.0);
+    if (d->kind == MLMC_LEGENDRE) {
+        long double c = 1.0L;   // leading coefficient of P_i: c_i = c_{i-1} (2i-1)/i
+        for (int i = 0; i < R; ++i) {
+            if (i >= 2) {
+                c = c * (long double)(2 * i - 1) / (long double)i;
+                coef[i] = (double)(((long double)(i - 1) * (i - 1)) / ((long double)(2 * i - 1) * (2 * i - 3)));
+            }
+            b->scale_c[i] = (double)c;
+        }
+    }
+    MLMC_HIP_CHECK(hipMalloc(&b->d_coef, sizeof(double) * R));
+    MLMC_HIP_CHECK(hipMalloc(&b->d_scale, sizeof(double) * R));
+    MLMC_HIP_CHECK(hipMemcpy(b->d_coef, coef.data(), sizeof(double) * R, hipMemcpyHostToDevice));
+    MLMC_HIP_CHECK(hipMemcpy(b->d_scale, b->scale_c.data(), sizeof(double) * R, hipMemcpyHostToDevice));
+    if (d->out_size > 0) {
+        b->matrix.assign(d->matrix, d->matrix + (size_t)d->out_size * R);
+        MLMC_HIP_CHECK(hipMalloc(&b->d_matrix, sizeof(double) * b->matrix.size()));
+        MLMC_HIP_CHECK(hipMemcpy(b->d_matrix, b->matrix.data(), sizeof(double) * b->matrix.size(), hipMemcpyHostToDevice));
+    }
+    *out = b;
+    return 0;
+}
+
+void mlmc_basis_destroy(mlmc_basis *b) {
+    if (!b) return;
+    if (b->d_coef) (void)hipFree(b->d_coef);
+    if (b->d_scale) (void)hipFree(b->d_scale);
+    if (b->d_matrix) (void)hipFree(b->d_matrix);
+    delete b;
+}
+
+int mlmc_basis_eval(const mlmc_basis *b, const double *x, int64_t n, int32_t size, double *out, int mem_kind) {
+    if (need_runtime()) return 1;
+    if (!b || (n > 0 && (!x || !out))) return fail("mlmc_basis_eval: null argument");
+    const int max_size = b->out_size > 0 ? b->out_size : b->p.size;
+    if (size <= 0 || size > max_size) return fail("mlmc_basis_eval: size out of range");
+    if (n == 0) return 0;
+    hipStream_t st = rt().stream;
+    if (mem_kind == MLMC_DEVICE) {
+        if (int rc = launch_eval(b, x, n, size, out)) return rc;
+        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        return 0;
+    }
+    double *d_x = nullptr, *d_o = nullptr;
+    MLMC_HIP_CHECK(hipMalloc(&d_x, sizeof(double) * (size_t)n));
+    MLMC_HIP_CHECK(hipMalloc(&d_o, sizeof(double) * (size_t)n * size));
+    MLMC_HIP_CHECK(hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    int rc = launch_eval(b, d_x, n, size, d_o);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out, d_o, sizeof(double) * (size_t)n * size, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(std::string("mlmc_basis_eval copy back: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_x);
+    (void)hipFree(d_o);
+    return rc;
+}
+
+// ---- accumulators ---------------------------------------------------------------------------
+int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32_t n_comp, mlmc_accum **out) {
+    if (need_runtime()) return 1;
+    if (!b || !out) return fail("mlmc_accum_create: null argument");
+    if (n_levels <= 0 || n_comp <= 0) return fail("mlmc_accum_create: n_levels and n_comp must be > 0");
+    if (mode != MLMC_MODE_MOMENTS && mode != MLMC_MODE_COV) return fail("mlmc_accum_create: unknown mode");
+    if (mode == MLMC_MODE_COV && b->out_size > 0)
+        return fail("mlmc_accum_create: covariance of TransformedMoments is not supported on the device path yet");
+    mlmc_accum *a = new (std::nothrow) mlmc_accum();
+    if (!a) return fail("out of memory");
+    a->basis = b;
+    a->n_levels = n_levels;
+    a->mode = mode;
+    a->n_comp = n_comp;
+    a->R = b->p.size;
+    a->Rout = b->out_size > 0 ? b->out_size : b->p.size;
+    a->RP = ((a->R + 15) / 16) * 16;
+    if (mode == MLMC_MODE_MOMENTS) {
+        a->K = (int64_t)n_comp * a->Rout;
+        a->int_width = 2 * (int64_t)a->R + (b->out_size > 0 ? (int64_t)a->RP * a->RP : 0);
+    } else {
+        a->K = (int64_t)n_comp * a->Rout * a->Rout;
+        a->int_width = 3 * (int64_t)a->RP * a->RP;
+    }
+    const size_t tot = (size_t)n_levels * n_comp * a->int_width;
+    if (hipMalloc(&a->d_totals, sizeof(double) * tot) != hipSuccess ||
+        hipMalloc(&a->d_counts, sizeof(int64_t) * 2 * n_levels) != hipSuccess ||
+        hipMalloc(&a->d_out_s, sizeof(double) * (size_t)n_levels * a->K) != hipSuccess ||
+        hipMalloc(&a->d_out_sp, sizeof(double) * (size_t)n_levels * a->K) != hipSuccess ||
+        hipMalloc(&a->d_out_n, sizeof(int64_t) * 2 * n_levels) != hipSuccess) {
+        mlmc_accum_destroy(a);
+        return fail("mlmc_accum_create: hipMalloc failed");
+    }
+    *out = a;
+    return mlmc_accum_reset(a);
+}
+
+int mlmc_accum_reset(mlmc_accum *a) {
+    if (need_runtime()) return 1;
+    if (!a) return fail("mlmc_accum_reset: null argument");
+    hipStream_t st = rt().stream;
+    MLMC_HIP_CHECK(hipMemsetAsync(a->d_totals, 0, sizeof(double) * (size_t)a->n_levels * a->n_comp * a->int_width, st));
+    MLMC_HIP_CHECK(hipMemsetAsync(a->d_counts, 0, sizeof(int64_t) * 2 * a->n_levels, st));
+    a->ev_used = 0;
+    a->ms_total = 0;
+    a->launches = 0;
+    a->alg_bytes = 0;
+    return 0;
+}
+
+void mlmc_accum_destroy(mlmc_accum *a) {
+    if (!a) return;
+    if (rt().ready) (void)hipStreamSynchronize(rt().stream);
+    void *ptrs[] = {a->d_totals, a->d_counts, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c,
+                    a->d_mask, a->d_out_s, a->d_out_sp, a->d_out_n};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : a->ev) (void)hipEventDestroy(e);
+    delete a;
+}
+
+int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const double *coarse, int64_t n, int mem_kind) {
+    if (need_runtime()) return 1;
+    if (!a) return fail("mlmc_accum_push: null argument");
+    if (level < 0 || level >= a->n_levels) return fail("mlmc_accum_push: level out of range");
+    if (n < 0) return fail("mlmc_accum_push: negative n");
+    if (n == 0) return 0;
+    if (!fine) return fail("mlmc_accum_push: fine is NULL");
+    if (n > ((int64_t)1 << 40)) return fail("mlmc_accum_push: chunk too large, split it");
+    hipStream_t st = rt().stream;
+    const size_t bytes = sizeof(double) * (size_t)n * a->n_comp;
+    const double *d_f = fine, *d_c = coarse;
+    if (mem_kind == MLMC_HOST) {
+        // staging buffers are reused across pushes: the previous push's kernels must have consumed them
+        if (bytes > a->stage_cap) {
+            MLMC_HIP_CHECK(hipStreamSynchronize(st));
+            if (a->d_stage_f) (void)hipFree(a->d_stage_f);
+            if (a->d_stage_c) (void)hipFree(a->d_stage_c);
+            a->d_stage_f = a->d_stage_c = nullptr;
+            a->stage_cap = 0;
+            MLMC_HIP_CHECK(hipMalloc(&a->d_stage_f, bytes));
+            MLMC_HIP_CHECK(hipMalloc(&a->d_stage_c, bytes));
+            a->stage_cap = bytes;
+        } else {
+            MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        MLMC_HIP_CHECK(hipMemcpyAsync(a->d_stage_f, fine, bytes, hipMemcpyHostToDevice, st));
+        d_f = a->d_stage_f;
+        if (coarse) {
+            MLMC_HIP_CHECK(hipMemcpyAsync(a->d_stage_c, coarse, bytes, hipMemcpyHostToDevice, st));
+            d_c = a->d_stage_c;
+        }
+        // pageable host memory: the copies above have been staged by the runtime when they return
+    } else if (mem_kind != MLMC_DEVICE) {
+        return fail("mlmc_accum_push: bad mem_kind");
+    }
+    const uint8_t *d_mask = nullptr;
+    bool count_in_kernel = true;
+    if (a->n_comp > 1) {
+        if (int rc = ensure((void **)&a->d_mask, &a->mask_cap, (size_t)n)) return rc;
+        if (int rc = launch_mask(a, d_f, d_c, n, a->d_mask, a->d_counts + 2 * (int64_t)level)) return rc;
+        d_mask = a->d_mask;
+        count_in_kernel = false;
+    }
+    for (int m = 0; m < a->n_comp; ++m) {
+        const double *f_m = d_f + (int64_t)m * n;
+        const double *c_m = d_c ? d_c + (int64_t)m * n : nullptr;
+        const bool count = count_in_kernel && m == 0;
+        int rc;
+        if (a->mode == MLMC_MODE_MOMENTS) {
+            rc = launch_moments_accum(a, level, m, f_m, c_m, d_mask, n, count);
+            if (!rc && a->basis->out_size > 0) rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, false, true);
+        } else {
+            rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, count, false);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, double *sp, int mem_kind) {
+    if (need_runtime()) return 1;
+    if (!a || !n || !n_rm || !s || !sp) return fail("mlmc_accum_finalize: null argument");
+    hipStream_t st = rt().stream;
+    int rc = (a->mode == MLMC_MODE_MOMENTS) ? launch_moments_finalize(a) : launch_cov_finalize(a);
+    if (rc) return rc;
+    const int L = a->n_levels;
+    const hipMemcpyKind kind = (mem_kind == MLMC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    // counts are stored interleaved (kept, removed) per level
+    std::vector<int64_t> cnt(2 * (size_t)L);
+    MLMC_HIP_CHECK(hipMemcpyAsync(cnt.data(), a->d_counts, sizeof(int64_t) * 2 * L, hipMemcpyDeviceToHost, st));
+    MLMC_HIP_CHECK(hipMemcpyAsync(s, a->d_out_s, sizeof(double) * (size_t)L * a->K, kind, st));
+    MLMC_HIP_CHECK(hipMemcpyAsync(sp, a->d_out_sp, sizeof(double) * (size_t)L * a->K, kind, st));
+    MLMC_HIP_CHECK(hipStreamSynchronize(st));
+    if (mem_kind == MLMC_DEVICE) {
+        std::vector<int64_t> k(L), r(L);
+        for (int l = 0; l < L; ++l) { k[l] = cnt[2 * l]; r[l] = cnt[2 * l + 1]; }
+        MLMC_HIP_CHECK(hipMemcpy(n, k.data(), sizeof(int64_t) * L, hipMemcpyHostToDevice));
+        MLMC_HIP_CHECK(hipMemcpy(n_rm, r.data(), sizeof(int64_t) * L, hipMemcpyHostToDevice));
+    } else {
+        for (int l = 0; l < L; ++l) { n[l] = cnt[2 * l]; n_rm[l] = cnt[2 * l + 1]; }
+    }
+    return timing_collect(a);
+}
+
+int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes) {
+    if (!a) return fail("mlmc_accum_kernel_time: null argument");
+    if (ms) *ms = a->ms_total;
+    if (launches) *launches = a->launches;
+    if (alg_bytes) *alg_bytes = a->alg_bytes;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Shared host/device declarations of libmlmc_hip.so (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mlmc_hip.h"
+
+namespace mlmc {
+
+constexpr int WAVE = 64;
+constexpr int ACC_THREADS = 256;   // 4 waves, one per SIMD of a CU
+constexpr int MAX_TERMS_PER_PASS = 64;
+
+// ---- error plumbing ---------------------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(const std::string &msg);
+#define MLMC_HIP_CHECK(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::mlmc::fail(std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+struct Runtime {
+    bool ready = false;
+    int device = -1;
+    int flags = 0;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+};
+Runtime &rt();
+
+// ---- device-visible basis parameters (passed by value to kernels) -------------------------
+struct BasisParams {
+    int kind;
+    int size;      // R of the underlying family
+    double shift, scale, ref0, ref1;
+    int is_log, is_clip;
+};
+
+}  // namespace mlmc
+
+struct mlmc_basis {
+    mlmc::BasisParams p;
+    int out_size = 0;                 // 0 = no transform
+    std::vector<double> matrix;       // [out_size][size] host copy
+    std::vector<double> scale_c;      // host: P_i = scale_c[i] * Q_i (Legendre: leading coefficients; else 1)
+    double *d_coef = nullptr;         // device: recurrence coefficients g_i [size]
+    double *d_scale = nullptr;        // device: scale_c [size]
+    double *d_matrix = nullptr;       // device: matrix [out_size][size]
+};
+
+struct mlmc_accum {
+    const mlmc_basis *basis = nullptr;
+    int n_levels = 0, mode = 0, n_comp = 1;
+    int R = 0;            // underlying family size
+    int Rout = 0;         // rows per component seen by the caller (transform applied)
+    int64_t K = 0;        // caller rows per level = n_comp * Rout (* Rout)
+    // internal totals per (level, component): MOMENTS: [2][R] (sum d, sum d^2) (+ [R][R] diff Gram if transform)
+    //                                         COV: [3][RP][RP] (G0, G1, G2)
+    int64_t int_width = 0;        // doubles per (level, comp)
+    double *d_totals = nullptr;   // [n_levels][n_comp][int_width]
+    int64_t *d_counts = nullptr;  // [n_levels][2]  (kept, removed)
+    // scratch
+    double *d_partials = nullptr; size_t partials_cap = 0;
+    int64_t *d_pcounts = nullptr; size_t pcounts_cap = 0;
+    double *d_stage_f = nullptr, *d_stage_c = nullptr; size_t stage_cap = 0;
+    uint8_t *d_mask = nullptr; size_t mask_cap = 0;
+    double *d_out_s = nullptr, *d_out_sp = nullptr; int64_t *d_out_n = nullptr;   // finalize outputs [L*K], [L*2]
+    // timing
+    std::vector<hipEvent_t> ev;   // pairs (start, stop)
+    size_t ev_used = 0;
+    double ms_total = 0;
+    int64_t launches = 0, alg_bytes = 0;
+    int RP = 0;  // COV: R padded to 16
+};
+
+namespace mlmc {
+// moments.hip
+int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, double *d_out);
+int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64_t n, uint8_t *d_mask, int64_t *d_counts_level);
+int launch_moments_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
+                         int64_t n, bool count);
+int launch_moments_finalize(mlmc_accum *a);
+// cov.hip
+int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
+                     int64_t n, bool count, bool diff_gram_only);
+int launch_cov_finalize(mlmc_accum *a);
+int ensure(void **p, size_t *cap, size_t bytes);
+int timing_begin(mlmc_accum *a);
+int timing_end(mlmc_accum *a);
+}  // namespace mlmc

@@ -1,0 +1,291 @@
+// Moment-covariance accumulation on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), gfx950.
+//
+// Reference (quantity_estimate.py:131-147 + :59-65): per sample the outer products f f^T and c c^T are
+// materialised ([2, M, n, R, R] doubles), subtracted, and summed together with their squares.
+// Here, with d = f - c and s = f + c (f, c the moment vectors of the fine / coarse value of one sample):
+//     f f^T - c c^T              = 1/2 (d s^T + s d^T)
+//     (f_i f_j - c_i c_j)^2      = 1/4 (d_i^2 s_j^2 + 2 d_i s_i d_j s_j + s_i^2 d_j^2)
+// so the level sums are three GEMM-shaped contractions over the sample index
+//     G0 = D^T S,   G1 = (D.D)^T (S.S),   G2 = (D.S)^T (D.S)
+//     sum (ff^T - cc^T) = 1/2 (G0 + G0^T),   sum (..)^2 = 1/4 (G1 + G1^T + 2 G2)
+// with no cancellation between large Gram matrices.  Level 0 (no coarse): d = s = f.
+//
+// Work split: a 256-thread workgroup owns a (16 T x 16 T) block of the output and walks batches of 64
+// samples.  Phase 1: two waves run the term recurrences (lane = (sample, fine|coarse)) and write the
+// values term-major into LDS (conflict-free: row stride 66 doubles).  Phase 2: every wave reads MFMA
+// fragments (A[i][k]: lane -> term i = lane & 15, sample k = lane >> 4) and issues 3 MFMAs per
+// (row tile, column tile, 4 samples).  Two workgroups per CU so one's phase 1 runs under the other's MFMAs.
+#include "device_basis.hpp"
+
+namespace mlmc {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int COV_BATCH = 64;
+constexpr int COV_LDS_STRIDE = 66;   // doubles per term row: == 2 (mod 32) -> ds_read_b64 fragments hit 32 distinct bank pairs
+
+// MODE 0: G0, G1, G2 (covariance mean + variance);  MODE 1: G = D^T D only (variance of transformed moments)
+template <int KIND, int T, bool PAIR, int MODE>
+__global__ __launch_bounds__(256, 2) void k_cov_accum(BasisParams bp, const double *__restrict__ coef,
+                                                      const double *__restrict__ fine,
+                                                      const double *__restrict__ coarse,
+                                                      const uint8_t *__restrict__ mask, int64_t n, int R,
+                                                      double *__restrict__ partials, int64_t *__restrict__ pcounts) {
+    constexpr int NT = 16 * T;                 // terms held in LDS
+    constexpr int NSL = 4 / T;                 // k-slices (waves sharing a row tile split the samples)
+    constexpr int NG = (MODE == 0) ? (PAIR ? 3 : 2) : 1;
+    __shared__ double lds_f[NT * COV_LDS_STRIDE];
+    __shared__ double lds_c[PAIR ? NT * COV_LDS_STRIDE : 1];
+    __shared__ int ldc[2][2];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int I = wave % T, kslice = wave / T;
+
+    v4f64 acc[NG][T];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[g][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    // phase-1 role of this lane
+    const int n_eval_waves = PAIR ? 2 : 1;
+    const bool evaluator = wave < n_eval_waves;
+    const int samp = PAIR ? (wave * 32 + (lane & 31)) : lane;   // sample slot in the batch
+    const bool is_coarse = PAIR && (lane >> 5);
+    const double *__restrict__ src = is_coarse ? coarse : fine;
+    double *__restrict__ dst = is_coarse ? lds_c : lds_f;
+    int n_keep = 0, n_rm = 0;
+
+    const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
+    int64_t batch = blockIdx.x;
+    double xv = 0.0;
+    uint8_t mv = 1;
+    if (evaluator && batch < n_batches) {
+        int64_t idx = batch * COV_BATCH + samp;
+        if (idx < n) { xv = src[idx]; if (mask) mv = mask[idx]; }
+    }
+    for (; batch < n_batches; batch += gridDim.x) {
+        // ---------------- phase 1: moment values of this batch -> LDS ----------------
+        if (evaluator) {
+            const int64_t idx = batch * COV_BATCH + samp;
+            const bool valid = idx < n;
+            bool keep;
+            double t = transform_value(bp, xv, keep);
+            keep = keep && valid && (mv != 0);
+            if (PAIR) {   // the shuffle must run in every lane (no short-circuit): fine lane l pairs with coarse lane l + 32
+                const int other = __shfl_xor((int)keep, 32, 64);
+                keep = keep && (other != 0);
+            }
+            if (!is_coarse) { n_keep += (int)keep; n_rm += (int)(valid && !keep); }
+            // prefetch the next batch's value
+            const int64_t nidx = (batch + gridDim.x) * COV_BATCH + samp;
+            if (nidx < n) { xv = src[nidx]; if (mask) mv = mask[nidx]; }
+            TermGen<KIND> g;
+            g.init(keep ? t : 0.0, keep ? 1.0 : 0.0);
+#pragma unroll 8
+            for (int i = 0; i < NT; ++i) {
+                double q = (i < R) ? g.next(i, coef) : 0.0;
+                dst[i * COV_LDS_STRIDE + samp] = q;
+            }
+        }
+        __syncthreads();
+        // ---------------- phase 2: MFMA over the batch ----------------
+        const int arow = 16 * I + (lane & 15);
+#pragma unroll 2
+        for (int ks = kslice; ks < COV_BATCH / 4; ks += NSL) {
+            const int col = 4 * ks + (lane >> 4);
+            double fa = lds_f[arow * COV_LDS_STRIDE + col];
+            double da = fa, sa = fa;
+            if (PAIR) {
+                double ca = lds_c[arow * COV_LDS_STRIDE + col];
+                da = fa - ca;
+                sa = fa + ca;
+            }
+            const double a1 = da * da, a2 = da * sa;
+#pragma unroll
+            for (int J = 0; J < T; ++J) {
+                const int brow = 16 * J + (lane & 15);
+                double fb = lds_f[brow * COV_LDS_STRIDE + col];
+                double db = fb, sb = fb;
+                if (PAIR) {
+                    double cb = lds_c[brow * COV_LDS_STRIDE + col];
+                    db = fb - cb;
+                    sb = fb + cb;
+                }
+                if (MODE == 0) {
+                    acc[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, sb, acc[0][J], 0, 0, 0);
+                    if (PAIR) {
+                        acc[1][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sb * sb, acc[1][J], 0, 0, 0);
+                        acc[2][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, db * sb, acc[2][J], 0, 0, 0);
+                    } else {
+                        acc[1][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, fb * fb, acc[1][J], 0, 0, 0);
+                    }
+                } else {
+                    acc[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, acc[0][J], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- write the workgroup's partial tiles ----------------
+    // partial row = (block, kslice); columns [g][row][col] with g in {G0, G1, G2} (MODE 0) or {G} (MODE 1)
+    constexpr int NGOUT = (MODE == 0) ? 3 : 1;
+    double *__restrict__ prow = partials + ((int64_t)blockIdx.x * NSL + kslice) * (NGOUT * NT * NT);
+#pragma unroll
+    for (int J = 0; J < T; ++J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + (lane >> 4) + 4 * r;
+            const int col = 16 * J + (lane & 15);
+            if (MODE == 0) {
+                prow[0 * NT * NT + row * NT + col] = acc[0][J][r];
+                if (PAIR) {
+                    prow[1 * NT * NT + row * NT + col] = acc[1][J][r];
+                    prow[2 * NT * NT + row * NT + col] = acc[2][J][r];
+                } else {   // level 0: d = s = f  ->  G1 = G2 = (F.F)^T (F.F)
+                    prow[1 * NT * NT + row * NT + col] = acc[1][J][r];
+                    prow[2 * NT * NT + row * NT + col] = acc[1][J][r];
+                }
+            } else {
+                prow[row * NT + col] = acc[0][J][r];
+            }
+        }
+    }
+    if (pcounts) {
+        n_keep = wave_sum_i(n_keep);
+        n_rm = wave_sum_i(n_rm);
+        if (lane == 0 && wave < 2) { ldc[wave][0] = n_keep; ldc[wave][1] = n_rm; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            int v = ldc[0][threadIdx.x] + (PAIR ? ldc[1][threadIdx.x] : 0);
+            pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = v;
+        }
+    }
+}
+
+// totals[g][row][col] (leading dimension RP) += sum over partial rows, fixed order.
+__global__ __launch_bounds__(1024) void k_reduce_cov(const double *__restrict__ partials, int nrows, int NT, int NG, int RP,
+                                                    double *__restrict__ totals) {
+    __shared__ double lds[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int width = NG * NT * NT;
+    const int col = blockIdx.x * 64 + c;
+    double acc = 0.0;
+    if (col < width)
+        for (int b = g; b < nrows; b += 16) acc += partials[(int64_t)b * width + col];
+    lds[g][c] = acc;
+    __syncthreads();
+    if (g == 0 && col < width) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += lds[k][c];
+        const int gi = col / (NT * NT), rem = col % (NT * NT);
+        const int row = rem / NT, cc = rem % NT;
+        if (row < RP && cc < RP) totals[(int64_t)gi * RP * RP + (int64_t)row * RP + cc] += v;
+    }
+}
+
+__global__ void k_reduce_counts2(const int64_t *__restrict__ pcounts, int nblocks, int64_t *__restrict__ counts) {
+    int64_t a = 0, b = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) { a += pcounts[2 * i]; b += pcounts[2 * i + 1]; }
+    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    if (threadIdx.x == 0) { counts[0] += a; counts[1] += b; }
+}
+
+template <int KIND, int T, int MODE>
+static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, const double *coef, const double *d_f, const double *d_c,
+                        const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
+    hipStream_t st = rt().stream;
+    if (pair)
+        hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+    else
+        hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+    MLMC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int KIND, int MODE>
+static int launch_cov_kind(const BasisParams &bp, int T, bool pair, int blocks, const double *coef, const double *d_f,
+                           const double *d_c, const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
+    switch (T) {
+        case 1: return launch_cov_t<KIND, 1, MODE>(bp, pair, blocks, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+        case 2: return launch_cov_t<KIND, 2, MODE>(bp, pair, blocks, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+        default: return launch_cov_t<KIND, 4, MODE>(bp, pair, blocks, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+    }
+}
+
+int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
+                     int64_t n, bool count, bool diff_gram_only) {
+    if (n == 0) return 0;
+    const int R = a->R;
+    if (R > 64) return fail("covariance accumulation supports at most 64 moments per pass on the device path (R > 64: not yet)");
+    hipStream_t st = rt().stream;
+    const int T = (R <= 16) ? 1 : (R <= 32 ? 2 : 4);
+    const int NT = 16 * T, NSL = 4 / T;
+    const int NG = diff_gram_only ? 1 : 3;
+    const bool pair = d_c != nullptr;
+    int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
+    int blocks = rt().n_cu * 2;
+    if (n_batches < blocks) blocks = (int)n_batches;
+    const size_t width = (size_t)NG * NT * NT;
+    if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * NSL * width)) return rc;
+    if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
+    int64_t *pc = count ? a->d_pcounts : nullptr;
+    const BasisParams &bp = a->basis->p;
+    const double *coef = a->basis->d_coef;
+    const bool timed = !diff_gram_only;
+    if (timed) if (int rc = timing_begin(a)) return rc;
+    int rc;
+#define MLMC_COV_DISPATCH(KIND)                                                                                          \
+    rc = diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, pair, blocks, coef, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
+                        : launch_cov_kind<KIND, 0>(bp, T, pair, blocks, coef, d_f, d_c, d_mask, n, R, a->d_partials, pc)
+    switch (bp.kind) {
+        case MLMC_LEGENDRE: MLMC_COV_DISPATCH(MLMC_LEGENDRE); break;
+        case MLMC_MONOMIAL: MLMC_COV_DISPATCH(MLMC_MONOMIAL); break;
+        case MLMC_FOURIER: MLMC_COV_DISPATCH(MLMC_FOURIER); break;
+        default: return fail("covariance: unsupported basis kind");
+    }
+#undef MLMC_COV_DISPATCH
+    if (rc) return rc;
+    if (timed) {
+        if (int rc2 = timing_end(a)) return rc2;
+        a->launches += 1;
+        a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
+    }
+    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0);
+    hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, a->d_partials, blocks * NSL, NT, NG,
+                       a->RP, totals);
+    MLMC_HIP_CHECK(hipGetLastError());
+    if (count) {
+        hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
+        MLMC_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+// out_s[lc][i][j] = 1/2 c_i c_j (G0_ij + G0_ji);  out_sp[lc][i][j] = 1/4 c_i^2 c_j^2 (G1_ij + G1_ji + 2 G2_ij)
+__global__ void k_cov_finalize(const double *__restrict__ totals, const double *__restrict__ scale_c, int R, int RP,
+                               int64_t int_width, double *__restrict__ out_s, double *__restrict__ out_sp) {
+    const int lc = blockIdx.y;
+    const double *G0 = totals + (int64_t)lc * int_width;
+    const double *G1 = G0 + (int64_t)RP * RP;
+    const double *G2 = G1 + (int64_t)RP * RP;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * R) return;
+    const int i = idx / R, j = idx % R;
+    const double ci = scale_c[i], cj = scale_c[j];
+    const double cc = ci * cj;
+    out_s[(int64_t)lc * R * R + idx] = 0.5 * cc * (G0[i * RP + j] + G0[j * RP + i]);
+    out_sp[(int64_t)lc * R * R + idx] = 0.25 * (cc * cc) * ((G1[i * RP + j] + G1[j * RP + i]) + 2.0 * G2[i * RP + j]);
+}
+
+int launch_cov_finalize(mlmc_accum *a) {
+    const int n_lc = a->n_levels * a->n_comp;
+    const int R = a->R;
+    hipLaunchKernelGGL(k_cov_finalize, dim3((R * R + 255) / 256, n_lc), dim3(256), 0, rt().stream, a->d_totals, a->basis->d_scale, R,
+                       a->RP, a->int_width, a->d_out_s, a->d_out_sp);
+    MLMC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mlmc

@@ -1,0 +1,95 @@
+// Device-side moment-function generators shared by the moments and covariance kernels.
+//
+// Reference semantics (mlmc/moments.py): t = (x - shift) * scale + ref0, optionally after log(x)
+// (:27-39, :69-70); with safe_eval a value whose t lies outside [ref0, ref1] becomes NaN (:58-67) and
+// the whole sample is later dropped by mask_nan_samples (quantity_estimate.py:6-14).  The transform is
+// evaluated with two separate roundings (the file is compiled with -ffp-contract=off) so that the
+// keep/drop decision is bit-identical to NumPy's; everything after the decision may use FMA.
+#pragma once
+#include "common.hpp"
+
+namespace mlmc {
+
+// Transformed value and keep flag of one raw sample value.
+__device__ __forceinline__ double transform_value(const BasisParams &bp, double x, bool &keep) {
+    if (bp.kind == MLMC_IDENTITY) {
+        keep = !(x != x);
+        return x;
+    }
+    double v = bp.is_log ? log(x) : x;
+    double t = (v - bp.shift) * bp.scale + bp.ref0;   // two roundings, no contraction
+    if (bp.is_clip)
+        keep = (t >= bp.ref0) && (t <= bp.ref1);      // NaN -> false
+    else
+        keep = !(t != t) && !(fabs(t) == __builtin_inf());   // x*0+1 is NaN for NaN/inf (legvander/polyvander v[0])
+    return t;
+}
+
+// Sequential generator of basis terms 0, 1, 2, ... for one value.  `w` (1 = kept, 0 = masked) is
+// folded into the seed so that a masked value yields exactly 0 in every term.
+//
+// LEGENDRE uses the monic recurrence Q_i = x Q_{i-1} - g_i Q_{i-2}, g_i = (i-1)^2 / ((2i-1)(2i-3)),
+// i.e. one multiply and one FMA per term instead of the five operations of
+// numpy.polynomial.legendre.legvander (P_i = (P_{i-1} x (2i-1) - P_{i-2} (i-1)) / i); the true
+// Legendre value is P_i = c_i Q_i with c_i the leading coefficient, applied once to the finished sums.
+template <int KIND>
+struct TermGen {
+    double x, p1, p2, c1, s1;
+    __device__ __forceinline__ void init(double x_, double w) {
+        x = x_;
+        p1 = w;   // term 0
+        p2 = 0.0;
+        if (KIND == MLMC_FOURIER) {
+            sincos(x_, &s1, &c1);
+            p1 = w;    // cos(0 t) * w
+            p2 = 0.0;  // sin(0 t) * w
+        }
+    }
+    // must be called with i = 0, 1, 2, ... in order
+    __device__ __forceinline__ double next(int i, const double *__restrict__ coef) {
+        if (i == 0) return p1;
+        if (KIND == MLMC_LEGENDRE) {
+            double q;
+            if (i == 1) q = x * p1;
+            else q = __builtin_fma(x, p1, -(coef[i] * p2));
+            p2 = p1;
+            p1 = q;
+            return q;
+        } else if (KIND == MLMC_MONOMIAL) {
+            p1 = p1 * x;
+            return p1;
+        } else if (KIND == MLMC_FOURIER) {
+            if (i & 1) {   // cos(k t), k = (i + 1) / 2: rotate (cos, sin) by t
+                double c = __builtin_fma(p1, c1, -(p2 * s1));
+                double s = __builtin_fma(p2, c1, p1 * s1);
+                p1 = c;
+                p2 = s;
+                return c;
+            }
+            return p2;     // sin(k t), k = i / 2
+        } else {           // IDENTITY has a single term
+            return 0.0;
+        }
+    }
+};
+
+// IDENTITY: the single "term" is the value itself.
+template <>
+struct TermGen<MLMC_IDENTITY> {
+    double v;
+    __device__ __forceinline__ void init(double x_, double w) { v = x_ * w; }
+    __device__ __forceinline__ double next(int, const double *__restrict__) { return v; }
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace mlmc

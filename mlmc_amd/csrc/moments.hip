@@ -1,0 +1,388 @@
+// Moment-function evaluation and the fused level-difference accumulation kernel (gfx950).
+//
+// Hot loop replaced (reference, one chunk of one level; quantity_estimate.py:43-65):
+//   moments_fn.eval_all(x)           -> [M, n, 2, R] temporaries (legvander: R ufunc passes)
+//   transpose/reshape                -> copy
+//   mask_nan_samples                 -> isnan pass over the expanded array + gather copy
+//   chunk[:, :, 0] - chunk[:, :, 1]  -> temporary
+//   np.sum(diff), np.sum(diff ** 2)  -> two more passes
+// Here: one pass over the raw fine/coarse arrays (16 B per sample pair, coalesced 8-B loads), the R-term
+// recurrences for fine and coarse kept in registers, per-lane fp64 accumulators for sum(d) and sum(d^2),
+// wave shuffles + LDS for the block partial, and a fixed-order second kernel for the grid reduction
+// (bitwise reproducible run to run).
+#include "device_basis.hpp"
+
+namespace mlmc {
+
+// ------------------------------------------------------------------------------------------
+// eval_all: out[i][r] (Moments.eval_all, moments.py:90-93) -- not a hot kernel; used by the PDF solver's
+// callers, plots and tests.  One thread per value.
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void k_eval(BasisParams bp, const double *__restrict__ coef, const double *__restrict__ scale_c,
+                       const double *__restrict__ x, int64_t n, int size, double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool keep;
+    double t = transform_value(bp, x[i], keep);
+    TermGen<KIND> g;
+    g.init(keep ? t : 0.0, 1.0);
+    const double nan = __builtin_nan("");
+    for (int r = 0; r < size; ++r) {
+        double q = g.next(r, coef);
+        if (KIND == MLMC_LEGENDRE) q *= scale_c[r];
+        out[i * size + r] = keep ? q : nan;
+    }
+}
+
+// out[i][j] = sum_r phi[i][r] * T[j][r]   (TransformedMoments._eval_all, moments.py:256-259)
+__global__ void k_apply_matrix(const double *__restrict__ phi, const double *__restrict__ T, int64_t n, int R0, int size,
+                               double *__restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * size) return;
+    int64_t i = idx / size;
+    int j = (int)(idx % size);
+    double acc = 0.0;
+    for (int r = 0; r < R0; ++r) acc = __builtin_fma(phi[i * R0 + r], T[(int64_t)j * R0 + r], acc);
+    out[idx] = acc;
+}
+
+int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, double *d_out) {
+    if (n == 0) return 0;
+    hipStream_t st = rt().stream;
+    int threads = 256;
+    int64_t blocks = (n + threads - 1) / threads;
+    const BasisParams &bp = b->p;
+    double *target = d_out;
+    double *d_tmp = nullptr;
+    int esize = size;
+    if (b->out_size > 0) {   // evaluate all R0 underlying terms, then apply the matrix
+        esize = bp.size;
+        MLMC_HIP_CHECK(hipMalloc(&d_tmp, sizeof(double) * (size_t)n * esize));
+        target = d_tmp;
+    }
+    switch (bp.kind) {
+        case MLMC_LEGENDRE: hipLaunchKernelGGL(k_eval<MLMC_LEGENDRE>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
+        case MLMC_MONOMIAL: hipLaunchKernelGGL(k_eval<MLMC_MONOMIAL>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
+        case MLMC_FOURIER: hipLaunchKernelGGL(k_eval<MLMC_FOURIER>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
+        case MLMC_IDENTITY: hipLaunchKernelGGL(k_eval<MLMC_IDENTITY>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
+        default: return fail("unknown basis kind");
+    }
+    MLMC_HIP_CHECK(hipGetLastError());
+    if (b->out_size > 0) {
+        int64_t tot = n * size;
+        hipLaunchKernelGGL(k_apply_matrix, dim3((tot + 255) / 256), dim3(256), 0, st, d_tmp, b->d_matrix, n, bp.size, size, d_out);
+        MLMC_HIP_CHECK(hipGetLastError());
+        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(hipFree(d_tmp));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// mask kernel for quantities with M > 1 components: a sample is dropped when ANY component of fine or
+// coarse is masked (mask_nan_samples reduces over axis 0, quantity_estimate.py:12).
+// ------------------------------------------------------------------------------------------
+__global__ void k_mask(BasisParams bp, const double *__restrict__ f, const double *__restrict__ c, int64_t n, int n_comp,
+                       uint8_t *__restrict__ mask, int64_t *__restrict__ counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int kept = 0, removed = 0;
+    if (i < n) {
+        bool keep = true;
+        for (int m = 0; m < n_comp; ++m) {
+            bool k1, k2 = true;
+            transform_value(bp, f[(int64_t)m * n + i], k1);
+            if (c) transform_value(bp, c[(int64_t)m * n + i], k2);
+            keep = keep && k1 && k2;
+        }
+        mask[i] = keep ? 1 : 0;
+        kept = keep;
+        removed = !keep;
+    }
+    kept = wave_sum_i(kept);
+    removed = wave_sum_i(removed);
+    if ((threadIdx.x & 63) == 0) {   // integer atomics: exact and order independent
+        atomicAdd((unsigned long long *)&counts[0], (unsigned long long)kept);
+        atomicAdd((unsigned long long *)&counts[1], (unsigned long long)removed);
+    }
+}
+
+int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64_t n, uint8_t *d_mask, int64_t *d_counts_level) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_mask, dim3((n + 255) / 256), dim3(256), 0, rt().stream, a->basis->p, d_f, d_c, n, a->n_comp, d_mask,
+                       d_counts_level);
+    MLMC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// The accumulation kernel.
+//   RT    : accumulators per lane for sum(d) and sum(d^2) (terms [t0, t0 + RT) of this pass)
+//   PAIR  : level >= 1 (fine and coarse) / level 0 (fine only)
+// Each lane walks the samples with a grid stride, two samples per trip (four independent recurrences
+// when PAIR) so that the fp64 pipe always has independent work; the next trip's loads are issued before
+// the current trip's arithmetic.
+// ------------------------------------------------------------------------------------------
+template <int KIND, int RT, bool PAIR, bool FIRST>
+__global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, const double *__restrict__ coef,
+                                                              const double *__restrict__ fine,
+                                                              const double *__restrict__ coarse,
+                                                              const uint8_t *__restrict__ mask, int64_t n, int t0_arg, int R,
+                                                              double *__restrict__ partials,
+                                                              int64_t *__restrict__ pcounts) {
+    const int t0 = FIRST ? 0 : t0_arg;   // first pass: every term index is a compile-time constant
+    double s[RT], sp[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
+    int n_keep = 0, n_rm = 0;
+
+    const int64_t T = (int64_t)gridDim.x * ACC_THREADS;
+    const int64_t gtid = (int64_t)blockIdx.x * ACC_THREADS + threadIdx.x;
+    const int n_terms = R - t0;   // terms of this pass actually wanted (<= RT)
+
+    int64_t i0 = gtid, i1 = gtid + T;
+    double f0 = 0, f1 = 0, c0 = 0, c1 = 0;
+    uint8_t m0 = 1, m1 = 1;
+    if (i0 < n) { f0 = fine[i0]; if (PAIR) c0 = coarse[i0]; if (mask) m0 = mask[i0]; }
+    if (i1 < n) { f1 = fine[i1]; if (PAIR) c1 = coarse[i1]; if (mask) m1 = mask[i1]; }
+
+    while (i0 < n) {
+        const bool v0 = true, v1 = i1 < n;
+        const double xf0 = f0, xf1 = f1, xc0 = c0, xc1 = c1;
+        const uint8_t mm0 = m0, mm1 = m1;
+        // prefetch the next trip
+        const int64_t j0 = i0 + 2 * T, j1 = i1 + 2 * T;
+        if (j0 < n) { f0 = fine[j0]; if (PAIR) c0 = coarse[j0]; if (mask) m0 = mask[j0]; }
+        if (j1 < n) { f1 = fine[j1]; if (PAIR) c1 = coarse[j1]; if (mask) m1 = mask[j1]; }
+
+        bool kf0, kf1, kc0 = true, kc1 = true;
+        double tf0 = transform_value(bp, xf0, kf0);
+        double tf1 = transform_value(bp, xf1, kf1);
+        double tc0 = 0, tc1 = 0;
+        if (PAIR) { tc0 = transform_value(bp, xc0, kc0); tc1 = transform_value(bp, xc1, kc1); }
+        bool k0 = v0 && kf0 && kc0 && (mm0 != 0);
+        bool k1 = v1 && kf1 && kc1 && (mm1 != 0);
+        n_keep += (int)k0 + (int)k1;
+        n_rm += (int)(v0 && !k0) + (int)(v1 && !k1);
+        const double w0 = k0 ? 1.0 : 0.0, w1 = k1 ? 1.0 : 0.0;
+
+        TermGen<KIND> gf0, gf1, gc0, gc1;
+        gf0.init(k0 ? tf0 : 0.0, w0);
+        gf1.init(k1 ? tf1 : 0.0, w1);
+        if (PAIR) { gc0.init(k0 ? tc0 : 0.0, w0); gc1.init(k1 ? tc1 : 0.0, w1); }
+
+        // terms below t0 (later passes of R > 64): advance the recurrences without accumulating
+        for (int i = 0; i < t0; ++i) {
+            gf0.next(i, coef); gf1.next(i, coef);
+            if (PAIR) { gc0.next(i, coef); gc1.next(i, coef); }
+        }
+#pragma unroll
+        for (int ib = 0; ib < RT; ib += 4) {
+            if (ib < n_terms) {   // wave-uniform guard, 4 terms at a time
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = ib + ii;
+                    double d0 = gf0.next(t0 + i, coef);
+                    double d1 = gf1.next(t0 + i, coef);
+                    if (PAIR) { d0 -= gc0.next(t0 + i, coef); d1 -= gc1.next(t0 + i, coef); }
+                    s[i] += d0;
+                    sp[i] = __builtin_fma(d0, d0, sp[i]);
+                    s[i] += d1;
+                    sp[i] = __builtin_fma(d1, d1, sp[i]);
+                }
+            }
+        }
+        i0 = j0;
+        i1 = j1;
+    }
+
+    // ---- block partial: wave shuffles, then the 4 waves through LDS in a fixed order ----
+    __shared__ double lds[4][2 * RT];
+    __shared__ int ldc[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        double a = wave_sum(s[i]);
+        double b = wave_sum(sp[i]);
+        if (lane == 0) { lds[wave][i] = a; lds[wave][RT + i] = b; }
+    }
+    n_keep = wave_sum_i(n_keep);
+    n_rm = wave_sum_i(n_rm);
+    if (lane == 0) { ldc[wave][0] = n_keep; ldc[wave][1] = n_rm; }
+    __syncthreads();
+    if (threadIdx.x < 2 * RT) {
+        const int j = threadIdx.x;
+        double v = ((lds[0][j] + lds[1][j]) + lds[2][j]) + lds[3][j];
+        partials[(int64_t)blockIdx.x * (2 * RT) + j] = v;
+    }
+    if (threadIdx.x < 2 && pcounts) {
+        int v = ldc[0][threadIdx.x] + ldc[1][threadIdx.x] + ldc[2][threadIdx.x] + ldc[3][threadIdx.x];
+        pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = v;
+    }
+}
+
+// totals[col] += sum over blocks of partials[block][col], fixed order: 64 columns x 16 row groups per block.
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials, int nblocks, int width,
+                                                         double *__restrict__ totals, int col_map_rt, int t0,
+                                                         int int_R) {
+    __shared__ double lds[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    double acc = 0.0;
+    if (col < width)
+        for (int b = g; b < nblocks; b += 16) acc += partials[(int64_t)b * width + col];
+    lds[g][c] = acc;
+    __syncthreads();
+    if (g == 0 && col < width) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += lds[k][c];
+        // map pass-local column (s: [0, RT), sp: [RT, 2 RT)) to the totals layout [2][int_R]
+        int which = col / col_map_rt, i = col % col_map_rt;
+        int term = t0 + i;
+        if (term < int_R) totals[(int64_t)which * int_R + term] += v;
+    }
+}
+
+__global__ void k_reduce_counts(const int64_t *__restrict__ pcounts, int nblocks, int64_t *__restrict__ counts) {
+    // one wave; exact integer sums
+    int64_t a = 0, b = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) { a += pcounts[2 * i]; b += pcounts[2 * i + 1]; }
+    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    if (threadIdx.x == 0) { counts[0] += a; counts[1] += b; }
+}
+
+template <int KIND, int RT>
+static int launch_accum_rt(mlmc_accum *a, bool pair, int blocks, const double *coef, const double *d_f, const double *d_c,
+                           const uint8_t *d_mask, int64_t n, int t0, int R, double *partials, int64_t *pcounts) {
+    hipStream_t st = rt().stream;
+    const BasisParams &bp = a->basis->p;
+#define MLMC_LAUNCH_ACC(P, F) hipLaunchKernelGGL((k_moments_accum<KIND, RT, P, F>), dim3(blocks), dim3(ACC_THREADS), 0, st, bp, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts)
+    if (pair && t0 == 0) MLMC_LAUNCH_ACC(true, true);
+    else if (pair) MLMC_LAUNCH_ACC(true, false);
+    else if (t0 == 0) MLMC_LAUNCH_ACC(false, true);
+    else MLMC_LAUNCH_ACC(false, false);
+#undef MLMC_LAUNCH_ACC
+    MLMC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int KIND>
+static int launch_accum_kind(mlmc_accum *a, int rt_sel, bool pair, int blocks, const double *coef, const double *d_f,
+                             const double *d_c, const uint8_t *d_mask, int64_t n, int t0, int R, double *partials,
+                             int64_t *pcounts) {
+    switch (rt_sel) {
+        case 4: return launch_accum_rt<KIND, 4>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
+        case 8: return launch_accum_rt<KIND, 8>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
+        case 16: return launch_accum_rt<KIND, 16>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
+        case 32: return launch_accum_rt<KIND, 32>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
+        case 48: return launch_accum_rt<KIND, 48>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
+        default: return launch_accum_rt<KIND, 64>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
+    }
+}
+
+static int pick_rt(int n_terms) {
+    const int opts[] = {4, 8, 16, 32, 48, 64};
+    for (int o : opts)
+        if (n_terms <= o) return o;
+    return 64;
+}
+
+// blocks per CU the register budget of an RT-instantiation admits (4 waves = 1 wave per SIMD per block)
+static int blocks_per_cu(int rt_sel) {
+    if (rt_sel <= 16) return 4;
+    if (rt_sel <= 32) return 2;
+    return 1;
+}
+
+int launch_moments_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
+                         int64_t n, bool count) {
+    if (n == 0) return 0;
+    hipStream_t st = rt().stream;
+    const int R = a->R;
+    const bool pair = d_c != nullptr;
+    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
+    int64_t *counts = a->d_counts + (int64_t)level * 2;
+    for (int t0 = 0; t0 < R; t0 += MAX_TERMS_PER_PASS) {
+        const int n_terms = (R - t0 < MAX_TERMS_PER_PASS) ? R - t0 : MAX_TERMS_PER_PASS;
+        const int rt_sel = pick_rt(n_terms);
+        int64_t want = (n + 2 * ACC_THREADS - 1) / (2 * ACC_THREADS);
+        int blocks = rt().n_cu * blocks_per_cu(rt_sel);
+        if (want < blocks) blocks = (int)want;
+        if (blocks < 1) blocks = 1;
+        const int width = 2 * rt_sel;
+        if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * width)) return rc;
+        if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
+        const bool do_count = count && t0 == 0;
+        int64_t *pc = do_count ? a->d_pcounts : nullptr;
+        if (int rc = timing_begin(a)) return rc;
+        int rc;
+        switch (a->basis->p.kind) {
+            case MLMC_LEGENDRE: rc = launch_accum_kind<MLMC_LEGENDRE>(a, rt_sel, pair, blocks, a->basis->d_coef, d_f, d_c, d_mask, n, t0, R, a->d_partials, pc); break;
+            case MLMC_MONOMIAL: rc = launch_accum_kind<MLMC_MONOMIAL>(a, rt_sel, pair, blocks, a->basis->d_coef, d_f, d_c, d_mask, n, t0, R, a->d_partials, pc); break;
+            case MLMC_FOURIER: rc = launch_accum_kind<MLMC_FOURIER>(a, rt_sel, pair, blocks, a->basis->d_coef, d_f, d_c, d_mask, n, t0, R, a->d_partials, pc); break;
+            case MLMC_IDENTITY: rc = launch_accum_rt<MLMC_IDENTITY, 4>(a, pair, blocks, a->basis->d_coef, d_f, d_c, d_mask, n, t0, R, a->d_partials, pc); break;
+            default: return fail("unknown basis kind");
+        }
+        if (rc) return rc;
+        if (int rc2 = timing_end(a)) return rc2;
+        a->launches += 1;
+        a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
+        const int rt_eff = (a->basis->p.kind == MLMC_IDENTITY) ? 4 : rt_sel;
+        hipLaunchKernelGGL(k_reduce_partials, dim3((2 * rt_eff + 63) / 64), dim3(1024), 0, st, a->d_partials, blocks, 2 * rt_eff,
+                           totals, rt_eff, t0, R);
+        MLMC_HIP_CHECK(hipGetLastError());
+        if (do_count) {
+            hipLaunchKernelGGL(k_reduce_counts, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, counts);
+            MLMC_HIP_CHECK(hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// finalize (MOMENTS): internal sums of the scaled basis -> caller rows.
+//   no transform : s_i = c_i S_i,  sp_i = c_i^2 SP_i
+//   transform T  : s_j = sum_i T_ji c_i S_i,  sp_j = sum_ik T_ji T_jk c_i c_k G_ik   (G = sum d d^T)
+// (sum_n (T d_n)_j^2 = (T G T^T)_jj: the per-sample matrix product of TransformedMoments._eval_all,
+//  moments.py:256-259, is applied once to the accumulated second moments instead of to every sample.)
+// ------------------------------------------------------------------------------------------
+__global__ void k_moments_finalize(const double *__restrict__ totals, const double *__restrict__ scale_c,
+                                   const double *__restrict__ T, int R, int RP, int Rout, int has_T, int64_t int_width,
+                                   int n_lc, double *__restrict__ out_s, double *__restrict__ out_sp) {
+    const int lc = blockIdx.x;   // (level, comp)
+    if (lc >= n_lc) return;
+    const double *tot = totals + (int64_t)lc * int_width;
+    for (int j = threadIdx.x; j < Rout; j += blockDim.x) {
+        double s, sp;
+        if (!has_T) {
+            const double c = scale_c[j];
+            s = c * tot[j];
+            sp = (c * c) * tot[R + j];
+        } else {
+            const double *G = tot + 2 * R;   // [RP][RP]
+            s = 0.0;
+            sp = 0.0;
+            for (int i = 0; i < R; ++i) {
+                const double ti = T[(int64_t)j * R + i] * scale_c[i];
+                s = __builtin_fma(ti, tot[i], s);
+                double row = 0.0;
+                for (int k = 0; k < R; ++k) row = __builtin_fma(T[(int64_t)j * R + k] * scale_c[k], G[(int64_t)i * RP + k], row);
+                sp = __builtin_fma(ti, row, sp);
+            }
+        }
+        out_s[(int64_t)lc * Rout + j] = s;
+        out_sp[(int64_t)lc * Rout + j] = sp;
+    }
+}
+
+int launch_moments_finalize(mlmc_accum *a) {
+    const int n_lc = a->n_levels * a->n_comp;
+    hipLaunchKernelGGL(k_moments_finalize, dim3(n_lc), dim3(128), 0, rt().stream, a->d_totals, a->basis->d_scale,
+                       a->basis->d_matrix, a->R, a->RP, a->Rout, a->basis->out_size > 0 ? 1 : 0, a->int_width, n_lc,
+                       a->d_out_s, a->d_out_sp);
+    MLMC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mlmc

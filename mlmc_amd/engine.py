@@ -1,0 +1,162 @@
+"""Level accumulators: thin Python face of mlmc_accum_* (include/mlmc_hip.h).
+
+One `LevelAccumulator` corresponds to one `estimate_mean()` call of the reference
+(mlmc/quantity/quantity_estimate.py:22-80): chunks of raw fine/coarse samples are pushed level by
+level, the HIP kernels evaluate the moment functions, mask out-of-domain / NaN samples and accumulate
+the level-difference sums; `finalize()` returns per-level counts and sums.
+
+Multi-GPU: every rank (one process per GPU) pushes its shard of each level's samples; `finalize()`
+then all-reduces the packed partial sums with torch.distributed (backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in CPU tests).  No other collective exists on this path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class _IdentityBasis:
+    """Plain quantity (no moments node): the single 'moment' is the value itself, mask = isnan."""
+    size = 1
+
+    def __init__(self):
+        self._handle = None
+
+    def _basis_handle(self):
+        if self._handle is None:
+            d = _lib.BasisDesc()
+            d.kind, d.size, d.shift, d.scale, d.ref0, d.ref1 = _lib.IDENTITY, 1, 0.0, 1.0, 0.0, 0.0
+            d.is_log = d.is_clip = d.out_size = 0
+            d.matrix = None
+            h = C.c_void_p()
+            _lib.check(_lib.lib().mlmc_basis_create(C.byref(d), C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None and _lib._lib is not None:
+                _lib._lib.mlmc_basis_destroy(self._handle)
+        except Exception:
+            pass
+
+
+def _dist_group_active(group):
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return False
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+class LevelAccumulator:
+    MOMENTS = _lib.MODE_MOMENTS
+    COV = _lib.MODE_COV
+
+    def __init__(self, moments_fn, n_levels, mode=_lib.MODE_MOMENTS, n_comp=1):
+        self._moments_fn = moments_fn if moments_fn is not None else _IdentityBasis()
+        self.n_levels = int(n_levels)
+        self.mode = int(mode)
+        self.n_comp = int(n_comp)
+        r = self._moments_fn.size
+        self.rows_per_comp = r if mode == _lib.MODE_MOMENTS else r * r
+        self.K = self.n_comp * self.rows_per_comp
+        h = C.c_void_p()
+        _lib.check(_lib.lib().mlmc_accum_create(self._moments_fn._basis_handle(), self.n_levels, self.mode, self.n_comp,
+                                                C.byref(h)))
+        self._h = h
+        self._keepalive = []
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and _lib._lib is not None:
+            _lib._lib.mlmc_accum_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        _lib.check(_lib.lib().mlmc_accum_reset(self._h))
+        self._keepalive = []
+
+    def push(self, level, fine, coarse=None):
+        """fine / coarse: [n] or [M, n] float64, NumPy arrays (host) or torch CUDA tensors (HBM resident)."""
+        if isinstance(fine, np.ndarray):
+            fine = _lib.as_f64(fine)
+            coarse = None if coarse is None else _lib.as_f64(coarse)
+        else:
+            assert fine.is_contiguous() and (coarse is None or coarse.is_contiguous())
+            self._keepalive.append((fine, coarse))   # launches are asynchronous
+        n = fine.shape[-1]
+        m = 1 if fine.ndim == 1 else fine.shape[0]
+        if m != self.n_comp:
+            raise ValueError("push: expected {} components, got {}".format(self.n_comp, m))
+        if coarse is not None and tuple(coarse.shape) != tuple(fine.shape):
+            raise ValueError("push: fine and coarse shapes differ")
+        _lib.check(_lib.lib().mlmc_accum_push(self._h, int(level), _lib.ptr(fine), _lib.ptr(coarse), int(n),
+                                              _lib.mem_kind(fine)))
+
+    def finalize(self, group=None, reduce=True):
+        """-> n[L], n_rm[L] (int64), s[L, K], sp[L, K] (float64); all-reduced over ranks when distributed."""
+        L, K = self.n_levels, self.K
+        if reduce and _dist_group_active(group):
+            n, n_rm, s, sp = self._finalize_distributed(group)
+        else:
+            n = np.empty(L, dtype=np.int64)
+            n_rm = np.empty(L, dtype=np.int64)
+            s = np.empty((L, K), dtype=np.float64)
+            sp = np.empty((L, K), dtype=np.float64)
+            _lib.check(_lib.lib().mlmc_accum_finalize(self._h, _lib.ptr(n), _lib.ptr(n_rm), _lib.ptr(s), _lib.ptr(sp), _lib.HOST))
+        self._keepalive = []
+        return n, n_rm, s, sp
+
+    def _finalize_distributed(self, group):
+        import torch
+        import torch.distributed as dist
+        L, K = self.n_levels, self.K
+        on_gpu = dist.get_backend(group) == "nccl"
+        dev = torch.device("cuda", _lib._bound_device) if on_gpu else torch.device("cpu")
+        counts = torch.empty(2 * L, dtype=torch.int64, device=dev)
+        sums = torch.empty(2 * L * K, dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().mlmc_accum_finalize(self._h, _lib.ptr(counts[:L]), _lib.ptr(counts[L:]), _lib.ptr(sums[:L * K]),
+                                                  _lib.ptr(sums[L * K:]), _lib.DEVICE if on_gpu else _lib.HOST))
+        counts, sums = allreduce_partials(counts, sums, group)
+        return counts[:L].copy(), counts[L:].copy(), sums[:L * K].reshape(L, K).copy(), sums[L * K:].reshape(L, K).copy()
+
+    def kernel_time(self):
+        """(ms, launches, algorithmic bytes) of the accumulation kernels since create/reset (needs FLAG_TIMING)."""
+        ms = C.c_double()
+        launches = C.c_int64()
+        nbytes = C.c_int64()
+        _lib.check(_lib.lib().mlmc_accum_kernel_time(self._h, C.byref(ms), C.byref(launches), C.byref(nbytes)))
+        return ms.value, launches.value, nbytes.value
+
+
+def allreduce_partials(counts, sums, group=None):
+    """The only exchange step of the path: one packed all-reduce (sum) of the int64 counts and one of the
+    fp64 partial sums over the ranks (RCCL over xGMI with backend "nccl"; "gloo" in CPU tests).
+    Takes torch tensors (device or host), returns NumPy arrays."""
+    import torch.distributed as dist
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return counts.cpu().numpy(), sums.cpu().numpy()
+
+
+def shard_bounds(n, rank, world_size):
+    """Contiguous slice [lo, hi) of a level's n samples owned by `rank`."""
+    lo = (n * rank) // world_size
+    hi = (n * (rank + 1)) // world_size
+    return lo, hi
+
+
+def level_stats(n, s, sp):
+    """Per-level mean and variance of the differences (quantity_estimate.py:70-77)."""
+    l_means, l_vars = [], []
+    with np.errstate(all="ignore"):
+        for nl, sl, spl in zip(n, s, sp):
+            l_means.append(sl / nl)
+            if nl > 1:
+                l_vars.append((spl - (sl ** 2 / nl)) / (nl - 1))
+            else:
+                l_vars.append(np.full(len(sl), np.inf))
+    return np.array(l_means), np.array(l_vars)
