@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: moment-evals/s of one complete MLMC moment estimate on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU, RCCL).  Workload at N = 1: BASELINE.json configs[1] -- 3 levels x 10^7 synthetic samples,
+Legendre n_moments = 32, mean + variance estimate; for N > 1 every rank holds its own 3 x 10^7 shard (weak
+scaling) and the per-level partial sums are all-reduced once per estimate.
+
+A "step" = one complete estimate over data already resident in HBM: accumulator reset, push of every level
+(fused transform + recurrence + mask + level-difference accumulation kernels), finalize (grid reduction, RCCL
+all-reduce for N > 1, copy of the [L, R] sums to the host) and the O(L R) mean/variance formulas.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector spec: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix spec
+
+CONFIGS = {
+    2: dict(L=3, n_per_level=10_000_000, R=32, mode="moments",
+            workload="BASELINE configs[1]: 3 levels x 1e7 synthetic samples per GPU, Legendre n_moments=32, mean+var estimate"),
+    3: dict(L=5, n_per_level=10_000_000, R=64, mode="cov",
+            workload="BASELINE configs[2]: 5 levels x 1e7 synthetic samples per GPU, Legendre n_moments=64, moment covariance mean+var"),
+}
+
+
+def synth_device(level, n, steps, seed, device):
+    """x ~ N(0,1); fine = x + h_l sqrt(1e-4+|x|); coarse = x + h_{l-1} sqrt(1e-4+|x|)
+    (formula of mlmc/sim/synth_simulation.py:37-46), generated in HBM."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + level)
+    x = torch.randn(n, dtype=torch.float64, device=device, generator=g)
+    root = torch.sqrt(1e-4 + torch.abs(x))
+    fine = (x + steps[level] * root).contiguous()
+    coarse = None if level == 0 else (x + steps[level - 1] * root).contiguous()
+    return fine, coarse
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
+
+    from mlmc_amd import _lib, Legendre
+    from mlmc_amd.engine import LevelAccumulator, level_stats
+    from oracle import oracle_np as onp   # checker + cpu_baseline leg only
+
+    _lib.init(local_rank, _lib.FLAG_TIMING)
+    dev = torch.device("cuda", local_rank)
+    cfg = CONFIGS[args.config]
+    L, n_l, R = cfg["L"], cfg["n_per_level"], cfg["R"]
+    dom = (-3.7190164854556804, 3.7190164854556804)   # scipy.stats.norm().ppf([1e-4, 1 - 1e-4]) (test/test_run.py:71)
+    steps = [s[0] for s in onp.determine_level_parameters(L, [0.5, 0.01])]
+    fn = Legendre(R, dom)
+    mode = LevelAccumulator.MOMENTS if cfg["mode"] == "moments" else LevelAccumulator.COV
+    acc = LevelAccumulator(fn, L, mode)
+
+    data = [synth_device(l, n_l, steps, 1234 + 1000 * rank, dev) for l in range(L)]
+    torch.cuda.synchronize()
+
+    def one_estimate():
+        acc.reset()
+        for l in range(L):
+            acc.push(l, data[l][0], data[l][1])
+        n, n_rm, s, sp = acc.finalize()           # RCCL all-reduce of the partial sums inside when world > 1
+        l_means, l_vars = level_stats(n, s, sp)
+        mean = np.sum(l_means, axis=0)
+        with np.errstate(all="ignore"):
+            var = np.sum(l_vars / n[:, None], axis=0)
+        return n, n_rm, mean, var
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_estimate()
+    # kernel-time bookkeeping of the timed region only
+    kt = [0.0, 0, 0]
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_estimate()
+        ms, launches, nbytes = acc.kernel_time()
+        kt[0] += ms
+        kt[1] += launches
+        kt[2] += nbytes
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        k = torch.tensor(kt, dtype=torch.float64, device=dev)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        kt = [float(k[0]), int(k[1]), int(k[2])]
+
+    n, n_rm, mean, var = res
+    samples_per_step = world * L * n_l
+    evals_per_step = samples_per_step * R
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = evals_per_step * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (HIP events on the library's stream) -------------------------
+    avg_launch_ms = kt[0] / max(kt[1], 1)
+    bytes_per_launch = kt[2] / max(kt[1], 1)
+    achieved_gbs = (kt[2] / 1e9) / (kt[0] / 1e3) if kt[0] > 0 else 0.0
+    # algorithmic flops, reference operation count: 14 R per pair, 8 R per level-0 sample;
+    # covariance adds 6 R^2 (three R x R x n contractions) per pair, 4 R^2 at level 0
+    pairs = (L - 1) * n_l
+    singles = n_l
+    if cfg["mode"] == "moments":
+        flops = (14 * R) * pairs + (8 * R) * singles
+        alu_peak, alu_bound, kname = FP64_VALU_PEAK_TFLOPS, "valu_f64", "k_moments_accum"
+    else:
+        flops = (14 * R + 6 * R * R) * pairs + (8 * R + 4 * R * R) * singles
+        alu_peak, alu_bound, kname = FP64_MFMA_PEAK_TFLOPS, "mfma_f64", "k_cov_accum"
+    step_kernel_s = (kt[0] / 1e3) / args.steps
+    achieved_tflops = flops / step_kernel_s / 1e12 if step_kernel_s > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": kname, "avg_launch_ms": round(avg_launch_ms, 5), "alg_bytes_per_launch": int(bytes_per_launch),
+        "launches_per_step": kt[1] // max(args.steps, 1),
+        # the kernel is fp64-ALU bound for R >= 12: the binding roof, reported beside the HBM one
+        "alu": {"bound": alu_bound, "achieved": round(achieved_tflops, 3), "peak": alu_peak, "unit": "TFLOP/s",
+                "frac": round(achieved_tflops / alu_peak, 4), "alg_flops_per_step": int(flops)},
+    }
+
+    out = {
+        "metric": "moment-evals/sec (samples x n_moments)", "value": value, "unit": "moment-evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": cfg["workload"], "levels": L, "samples_per_level_per_gpu": n_l, "n_moments": R,
+                   "basis": "Legendre", "estimate": cfg["mode"], "exchange": "all-reduce of [L,(2+2K)] partial sums" if world > 1 else "none"},
+        "roofline": roofline,
+        "result_check": {"mean0": float(np.ravel(mean)[0]), "var0": float(np.ravel(var)[0]), "n_removed": [int(v) for v in n_rm]},
+    }
+
+    # ---- CPU baseline + parity gate on a bounded sample (rank 0, N = 1 only) ---------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_stats)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_stats):
+    """NumPy restatement of the reference path (oracle, same operation order as the reference: legvander,
+    transpose, NaN mask, fine - coarse, two np.sum), single thread like the reference, streamed in chunks."""
+    L, R = cfg["L"], cfg["R"]
+    if cfg["mode"] == "moments":
+        n_s, chunk = 10_000_000, 250_000   # the full configs[1] size: about 10 s of NumPy on one core
+        rows = onp.moments_rows
+    else:
+        n_s, chunk = 6_000, 1_000       # the reference form materialises [2, n, R, R] per chunk
+        rows = onp.covariance_rows
+    b = onp.Basis(onp.LEGENDRE, R, dom)
+    host = [onp.synth_level_samples(l, n_s, steps, seed=4321) for l in range(L)]
+    level_chunks = []
+    for l, (f, c) in enumerate(host):
+        cl = []
+        for i in range(0, n_s, chunk):
+            x = np.stack([f[i:i + chunk], (c if c is not None else f)[i:i + chunk]], axis=-1)[None]
+            cl.append(x[:, :, :1] if l == 0 else x)
+        level_chunks.append(cl)
+    t0 = time.perf_counter()
+    ref = onp.estimate_mean(level_chunks, lambda x: rows(b, x))
+    cpu_s = time.perf_counter() - t0
+    cpu = {"value": L * n_s * R / cpu_s, "unit": "moment-evals/s", "cores": 1, "kind": "port",
+           "sample": "{} levels x {} samples, Legendre R={}, {} estimate, NumPy restatement of the reference path "
+                     "(oracle/oracle_np.py), chunks of {}; {:.2f} s on 1 of {} host cores".format(
+                         L, n_s, R, cfg["mode"], chunk, cpu_s, os.cpu_count())}
+    mode = LevelAccumulator.MOMENTS if cfg["mode"] == "moments" else LevelAccumulator.COV
+    acc = LevelAccumulator(fn, L, mode)
+    for l, (f, c) in enumerate(host):
+        acc.push(l, f, c)
+    n, n_rm, s, sp = acc.finalize()
+    l_means, l_vars = level_stats(n, s, sp)
+    rms = np.sqrt(np.abs(ref.sums_sq) / np.maximum(ref.n_samples[:, None], 1))
+    err_mean = float(np.max(np.abs(l_means - ref.l_means) / np.maximum(np.abs(ref.l_means), rms + 1e-300)))
+    err_var = float(np.max(np.abs(l_vars - ref.l_vars) / np.maximum(np.abs(ref.l_vars), 1e-300)))
+    parity = {"counts_bit_exact": bool(np.array_equal(n, ref.n_samples) and np.array_equal(n_rm, ref.n_rm_samples)),
+              "max_rel_err_l_means": err_mean, "max_rel_err_l_vars": err_var, "tolerance": 1e-10,
+              "ok": bool(np.array_equal(n, ref.n_samples) and np.array_equal(n_rm, ref.n_rm_samples)
+                         and err_mean <= 1e-10 and err_var <= 1e-10)}
+    return cpu, parity
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,49 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol include/mlmc_hip.h declares, and the
+product fails loudly (no CPU fallback) when no GPU is present."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mlmc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mlmc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mlmc_amd import _lib
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), name
+        assert name in _lib.SIGNATURES, "ctypes prototype missing for " + name
+    assert set(_lib.SIGNATURES) == set(names)
+    assert lib.mlmc_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mlmc_amd import _lib, Legendre
+    with pytest.raises(_lib.MlmcHipError, match="no HIP device"):
+        _lib.init(0)
+    fn = Legendre(4, (-1.0, 1.0))
+    assert fn.size == 4 and fn.ref_domain == (-1, 1)
+    with pytest.raises(_lib.MlmcHipError):
+        fn.eval_all([0.0, 0.5])
+
+
+def test_product_does_not_import_oracle():
+    """the oracle is test infrastructure: nothing under mlmc_amd/ may import it"""
+    pkg = os.path.join(ROOT, "mlmc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

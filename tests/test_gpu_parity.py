@@ -1,0 +1,361 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the golden
+vectors generated from the imported reference (tests/golden) and against the oracle on seeded inputs.
+
+Tolerances: counts / masks / indices bit-exact; fp64 values |a - b| <= 1e-10 * max(|b|, rms of the level)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c, oracle_np as onp
+from tests.util import close, level_arrays, to_chunks
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mlmc_amd import _lib
+    _lib.init(0)
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def g1():
+    return np.load(os.path.join(GOLDEN, "G1_basis.npz"))
+
+
+@pytest.fixture(scope="module")
+def g2():
+    return np.load(os.path.join(GOLDEN, "G2_estimate_mean.npz"))
+
+
+def _same_nan(a, b):
+    return np.array_equal(np.isnan(a), np.isnan(b))
+
+
+def _vals_close(a, b, tol=TOL):
+    m = ~np.isnan(b)
+    # basis values are O(1) (Legendre, Fourier) or grow like t^k (monomial, safe_eval False): relative to max(1, |b|)
+    return np.all(np.abs(a[m] - b[m]) <= tol * np.maximum(1.0, np.abs(b[m])))
+
+
+def test_basis_eval_golden(hip, g1):
+    from mlmc_amd import Legendre, Monomial, Fourier
+    dom = tuple(g1["dom"])
+    for R in (1, 2, 5, 10, 32, 64):
+        for safe in (True, False):
+            g = g1["grid"] if safe else g1["grid_nosafe"]
+            for cls, name in ((Legendre, "legendre"), (Monomial, "monomial")):
+                got = cls(R, dom, safe_eval=safe).eval_all(g)
+                ref = g1[f"{name}_R{R}_safe{int(safe)}"]
+                assert got.shape == ref.shape
+                assert _same_nan(got, ref), (name, R, safe)
+                if name == "monomial" and not safe:
+                    m = np.isfinite(ref) & (np.abs(ref) < 1e200)
+                    assert np.all(np.abs(got[m] - ref[m]) <= 1e-10 * np.maximum(1.0, np.abs(ref[m])))
+                else:
+                    assert _vals_close(got, ref), (name, R, safe)
+    for R in (1, 2, 5, 6, 33):
+        got = Fourier(R, dom).eval_all(g1["grid"])
+        ref = g1[f"fourier_R{R}_safe1"]
+        # reference quirk: Fourier column 0 is the constant 1 even for masked (NaN) inputs (moments.py:156);
+        # the device path marks the whole row NaN (the sample is dropped by mask_nan_samples either way)
+        assert _same_nan(got[:, 1:], ref[:, 1:]) and _vals_close(got[:, 1:], ref[:, 1:])
+    assert np.array_equal(Legendre(4, (-1.0, 1.0))(np.array([0.0, 0.25, 0.5, 0.75, 1.0])), g1["kat_legendre"]) or \
+        _vals_close(Legendre(4, (-1.0, 1.0))(np.array([0.0, 0.25, 0.5, 0.75, 1.0])), g1["kat_legendre"], 1e-15)
+
+
+def test_basis_eval_log_ref_nd_transformed(hip, g1):
+    from mlmc_amd import Legendre, Monomial, TransformedMoments
+    ldom, dom = tuple(g1["ldom"]), tuple(g1["dom"])
+    for R in (5, 32):
+        for cls, name in ((Legendre, "legendre"), (Monomial, "monomial")):
+            got = cls(R, ldom, log=True).eval_all(g1["lgrid"])
+            ref = g1[f"{name}_log_R{R}"]
+            assert _same_nan(got, ref) and _vals_close(got, ref)
+    got = Legendre(7, dom, ref_domain=(-0.5, 0.75)).eval_all(g1["grid"])
+    assert _same_nan(got, g1["legendre_ref_R7"]) and _vals_close(got, g1["legendre_ref_R7"])
+    got = Monomial(7, dom, ref_domain=(-1.0, 2.0)).eval_all(g1["grid"])
+    assert _same_nan(got, g1["monomial_ref_R7"]) and _vals_close(got, g1["monomial_ref_R7"])
+    got = Legendre(9, dom).eval_all(g1["x3"])
+    assert got.shape == (3, 17, 2, 9) and _same_nan(got, g1["legendre_x3_R9"]) and _vals_close(got, g1["legendre_x3_R9"])
+    tm = TransformedMoments(Legendre(9, dom), g1["tm_matrix"])
+    got = tm.eval_all(g1["x3"])
+    ref = g1["transformed_x3"]
+    assert _same_nan(got, ref) and np.all(np.abs(got - ref)[~np.isnan(ref)] <= 1e-10 * 10)
+    got = tm.eval_all(g1["grid"], 4)
+    ref = g1["transformed_grid_size4"]
+    assert got.shape == ref.shape and _same_nan(got, ref)
+    fn = Legendre(6, dom)
+    for key, got in (("legendre_single3", fn.eval_single_moment(3, g1["grid"])), ("legendre_eval3", fn.eval(3, g1["grid"])),
+                     ("legendre_diff", fn.eval_diff(g1["grid"])), ("legendre_diff2", fn.eval_diff2(g1["grid"])),
+                     ("legendre_der1", fn.eval_all_der(g1["grid"], degree=1)),
+                     ("monomial_eval3", Monomial(6, dom).eval(3, g1["grid"]))):
+        ref = g1[key]
+        assert got.shape == ref.shape and _same_nan(got, ref), key
+        m = ~np.isnan(ref)
+        assert np.all(np.abs(got[m] - ref[m]) <= 1e-10 * np.maximum(1.0, np.abs(ref[m]))), key
+
+
+def _run_accum(fn, levels, mode=None, n_comp=1):
+    from mlmc_amd.engine import LevelAccumulator
+    acc = LevelAccumulator(fn, len(levels), LevelAccumulator.MOMENTS if mode is None else mode, n_comp=n_comp)
+    for l, (f, c) in enumerate(levels):
+        acc.push(l, f if n_comp > 1 else np.ravel(f), c if (c is None or n_comp > 1) else np.ravel(c))
+    return acc.finalize()
+
+
+def _check_against(n, n_rm, s, sp, ref):
+    from mlmc_amd.engine import level_stats
+    assert np.array_equal(n, ref.n_samples), (n, ref.n_samples)
+    assert np.array_equal(n_rm, ref.n_rm_samples), (n_rm, ref.n_rm_samples)
+    l_means, l_vars = level_stats(n, s, sp)
+    rms = np.sqrt(np.abs(ref.sums_sq) / np.maximum(ref.n_samples[:, None], 1))
+    assert close(l_means, ref.l_means, rms, TOL)
+    assert close(l_vars, ref.l_vars, None, TOL)
+    mean = np.sum(l_means, axis=0)
+    with np.errstate(all="ignore"):
+        var = np.sum(l_vars / n[:, None], axis=0)
+    return mean, var
+
+
+@pytest.mark.parametrize("tag", ["L3", "L5", "L3nan", "L1"])
+def test_estimate_moments_golden(hip, g2, tag):
+    """estimate_mean(moments(q, Legendre)) against outputs of the imported reference (G2)."""
+    from mlmc_amd import Legendre, Monomial
+    dom = tuple(g2["domain"])
+    N, steps, nan_every = g2[f"{tag}_N"], g2[f"{tag}_steps"], int(g2[f"{tag}_nan_every"])
+    levels = level_arrays(N, steps, 1, nan_every)
+    for R in (5, 32, 64):
+        n, n_rm, s, sp = _run_accum(Legendre(R, dom), levels)
+        key = f"{tag}_leg{R}_b1"
+        assert np.array_equal(n, g2[key + "_n"]) and np.array_equal(n_rm, g2[key + "_n_rm"])
+        b = onp.Basis(onp.LEGENDRE, R, dom)
+        ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(b, x))
+        mean, var = _check_against(n, n_rm, s, sp, ref)
+        rms = np.sqrt(np.sum(np.abs(ref.sums_sq) / np.maximum(ref.n_samples[:, None], 1), axis=0))
+        assert close(mean, g2[key + "_mean"], rms, TOL)
+        assert close(var, g2[key + "_var"], None, TOL)
+        assert mean[0] == 1.0 and var[0] == 0.0          # reference: test/test_run.py:106-107
+    n, n_rm, s, sp = _run_accum(Monomial(6, dom), levels)
+    b = onp.Basis(onp.MONOMIAL, 6, dom)
+    ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(b, x))
+    mean, var = _check_against(n, n_rm, s, sp, ref)
+    assert close(mean, g2[f"{tag}_mono6_mean"], 1.0, TOL) and close(var, g2[f"{tag}_mono6_var"], None, TOL)
+    # plain quantity mean (no moments node): IDENTITY kind
+    n, n_rm, s, sp = _run_accum(None, levels)
+    ref = onp.estimate_mean(to_chunks(levels))
+    mean, var = _check_against(n, n_rm, s, sp, ref)
+    assert np.array_equal(n_rm, g2[f"{tag}_plain_n_rm"])
+    assert close(mean, g2[f"{tag}_plain_mean"].ravel(), 1.0, TOL) and close(var, g2[f"{tag}_plain_var"].ravel(), None, TOL)
+
+
+def test_estimate_moments_vector_quantity(hip, g2):
+    """M = 4 components: a sample is dropped when any component of fine or coarse is masked."""
+    from mlmc_amd import Legendre
+    tag = "L3M4"
+    dom = tuple(g2["domain"])
+    levels = level_arrays(g2[f"{tag}_N"], g2[f"{tag}_steps"], 4, int(g2[f"{tag}_nan_every"]))
+    n, n_rm, s, sp = _run_accum(Legendre(5, dom), levels, n_comp=4)
+    key = f"{tag}_leg5_b1"
+    assert np.array_equal(n, g2[key + "_n"]) and np.array_equal(n_rm, g2[key + "_n_rm"])
+    b = onp.Basis(onp.LEGENDRE, 5, dom)
+    ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(b, x))
+    mean, var = _check_against(n, n_rm, s, sp, ref)
+    assert close(mean, g2[key + "_mean"].ravel(), 1.0, TOL) and close(var, g2[key + "_var"].ravel(), None, TOL)
+
+
+@pytest.mark.parametrize("tag", ["L3", "L3nan", "L1"])
+def test_estimate_covariance_golden(hip, g2, tag):
+    from mlmc_amd import Legendre
+    from mlmc_amd.engine import LevelAccumulator
+    g3 = np.load(os.path.join(GOLDEN, "G3_cov.npz"))
+    dom = tuple(g2["domain"])
+    N, steps, nan_every = g2[f"{tag}_N"], g2[f"{tag}_steps"], int(g2[f"{tag}_nan_every"])
+    levels = level_arrays(N, steps, 1, nan_every)
+    for R in (8, 16, 64):
+        key = f"{tag}_cov{R}"
+        Ncov = g3[key + "_Ncov"]
+        lv = [(f[:, :k], None if c is None else c[:, :k]) for (f, c), k in zip(levels, Ncov)]
+        n, n_rm, s, sp = _run_accum(Legendre(R, dom), lv, mode=LevelAccumulator.COV)
+        assert np.array_equal(n, g3[key + "_n"]) and np.array_equal(n_rm, g3[key + "_n_rm"])
+        b = onp.Basis(onp.LEGENDRE, R, dom)
+        ref = onp.estimate_mean(to_chunks(lv), lambda x: onp.covariance_rows(b, x))
+        mean, var = _check_against(n, n_rm, s, sp, ref)
+        rms = np.sqrt(np.sum(np.abs(ref.sums_sq) / np.maximum(ref.n_samples[:, None], 1), axis=0))
+        assert close(mean.reshape(R, R), g3[key + "_mean"], rms.reshape(R, R), TOL)
+        assert close(var.reshape(R, R), g3[key + "_var"], None, TOL)
+        cov = mean.reshape(R, R)
+        assert np.array_equal(cov, cov.T)                       # exactly symmetric by construction
+        n2, _, s2, sp2 = _run_accum(Legendre(R, dom), lv)      # cov[:, 0] == moment means (test_quantity_concept.py:613)
+        from mlmc_amd.engine import level_stats
+        mom_mean = np.sum(level_stats(n2, s2, sp2)[0], axis=0)
+        assert close(cov[:, 0], mom_mean, 1.0, 1e-12)
+
+
+def test_reference_golden_chain(hip):
+    """The reference's own golden vector (test/test_sampling_pools.py:18,85-87)."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.engine import level_stats
+    with open(os.path.join(GOLDEN, "G7_chain.json")) as f:
+        g7 = json.load(f)
+    levels = []
+    for l, lev in enumerate(g7["levels"]):
+        fine = np.array(lev["fine"])[:, 0]
+        coarse = np.array(lev["coarse"])[:, 0]
+        levels.append((fine, None if l == 0 else coarse))
+    n, n_rm, s, sp = _run_accum(Legendre(5, tuple(g7["domain"])), levels)
+    l_means, l_vars = level_stats(n, s, sp)
+    means = np.sum(l_means, axis=0)
+    vars_ = np.sum(l_vars / n[:, None], axis=0)
+    assert means[0] == 1 and vars_[0] == 0
+    assert np.allclose(g7["ref_means_test_sampling_pools_py_18"], means, atol=1e-5)
+    assert close(means, g7["means"], 1.0, TOL) and close(vars_, g7["vars"], None, 1e-9)
+
+
+@pytest.mark.parametrize("R", [1, 3, 17, 48, 65, 100, 130])
+def test_moment_counts_and_multi_pass(hip, R):
+    """ragged sizes, every register-tile instantiation, and R > 64 (several passes over the terms)"""
+    from mlmc_amd import Legendre
+    dom = (-3.7, 3.7)
+    N = [7001, 4099, 513, 1]
+    steps = [0.5, 0.1, 0.03, 0.01]
+    levels = level_arrays(N, steps, 1, 5)
+    n, n_rm, s, sp = _run_accum(Legendre(R, dom), levels)
+    b = onp.Basis(onp.LEGENDRE, R, dom)
+    ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(b, x))
+    _check_against(n, n_rm, s, sp, ref)
+    assert s[0, 0] == float(n[0])                     # P0 sums are exact counts
+
+
+def test_fourier_and_transformed_accumulate(hip):
+    from mlmc_amd import Fourier, Legendre, TransformedMoments
+    dom = (-3.7, 3.7)
+    levels = level_arrays([5000, 3000, 1001], [0.5, 0.07, 0.01], 1, 9)
+    # Fourier: the reference cannot run this inside qe.moments (np.outer); the oracle evaluates the same
+    # columns sample by sample
+    R = 9
+    n, n_rm, s, sp = _run_accum(Fourier(R, dom), levels)
+    b = onp.Basis(onp.FOURIER, R, dom)
+
+    def rows(x):
+        flat = onp.eval_all(b, x.reshape(-1)).reshape(x.shape + (R,))
+        flat[np.isnan(flat).any(axis=-1)] = np.nan
+        return flat.transpose((0, 3, 1, 2)).reshape(R, x.shape[1], x.shape[2])
+    ref = onp.estimate_mean(to_chunks(levels), rows)
+    _check_against(n, n_rm, s, sp, ref)
+    # TransformedMoments: variance through the accumulated second moments T G T^T
+    rng = np.random.default_rng(3)
+    for R0, R1 in ((9, 6), (33, 33), (64, 40)):
+        mat = rng.normal(size=(R1, R0)) / np.sqrt(R0)
+        mat[0] = 0
+        mat[0, 0] = 1
+        n, n_rm, s, sp = _run_accum(TransformedMoments(Legendre(R0, dom), mat), levels)
+        bt = onp.Basis(onp.LEGENDRE, R0, dom, matrix=mat)
+        ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(bt, x))
+        _check_against(n, n_rm, s, sp, ref)
+
+
+def test_edge_cases(hip):
+    from mlmc_amd import Legendre, _lib
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-1.0, 1.0)
+    fn = Legendre(7, dom)
+    acc = LevelAccumulator(fn, 2)
+    acc.push(0, np.zeros(0))                                   # empty chunk
+    acc.push(1, np.zeros(0), np.zeros(0))
+    n, n_rm, s, sp = acc.finalize()
+    assert n.tolist() == [0, 0] and n_rm.tolist() == [0, 0] and not s.any() and not sp.any()
+    # everything masked
+    acc.reset()
+    acc.push(0, np.full(1000, 5.0))
+    acc.push(1, np.full(77, np.nan), np.zeros(77))
+    n, n_rm, s, sp = acc.finalize()
+    assert n.tolist() == [0, 0] and n_rm.tolist() == [1000, 77] and not s.any()
+    # boundary values: end points kept, one ulp outside dropped, -0.0, tiny
+    x = np.array([-1.0, 1.0, np.nextafter(1.0, 2.0), np.nextafter(-1.0, -2.0), -0.0, 1e-300, np.inf, -np.inf, np.nan])
+    acc.reset()
+    acc.push(0, x)
+    n, n_rm, s, sp = acc.finalize()
+    assert n[0] == 4 and n_rm[0] == 5
+    # chunked pushes == one push (additivity), finalize idempotent
+    rng = np.random.default_rng(0)
+    f = rng.uniform(-1.1, 1.1, 30001)
+    c = f + 0.01 * rng.normal(size=f.size)
+    acc.reset()
+    acc.push(1, f, c)
+    r1 = acc.finalize()
+    r1b = acc.finalize()
+    acc.reset()
+    for lo, hi in ((0, 1), (1, 4097), (4097, 30001)):
+        acc.push(1, f[lo:hi], c[lo:hi])
+    r2 = acc.finalize()
+    for a, b_, c_ in zip(r1, r1b, r2):
+        assert np.array_equal(a, b_)
+    assert np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1])
+    assert close(r1[2], r2[2], 1.0, 1e-12) and close(r1[3], r2[3], 1.0, 1e-12)
+    # fine == coarse -> all level differences are exactly zero
+    acc.reset()
+    acc.push(1, f, f.copy())
+    n, n_rm, s, sp = acc.finalize()
+    assert not s[1].any() and not sp[1].any()
+    # argument errors come back as exceptions
+    with pytest.raises(_lib.MlmcHipError):
+        acc.push(5, f)
+    with pytest.raises(ValueError):
+        acc.push(1, f, c[:10])
+
+
+def test_device_resident_inputs_and_large_property(hip):
+    """BASELINE-size run (3 x 1e7, R = 32) from HBM-resident tensors: size-independent properties +
+    C-oracle parity on a 2e6 prefix."""
+    import torch
+    from mlmc_amd import Legendre
+    from mlmc_amd.engine import LevelAccumulator, level_stats
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    L, n_l, R = 3, 10_000_000, 32
+    steps = [s[0] for s in onp.determine_level_parameters(L, [0.5, 0.01])]
+    fn = Legendre(R, dom)
+    acc = LevelAccumulator(fn, L)
+    host = [onp.synth_level_samples(l, n_l, steps, seed=99) for l in range(L)]
+    dev = [(torch.from_numpy(f).cuda(), None if c is None else torch.from_numpy(c).cuda()) for f, c in host]
+    for l in range(L):
+        acc.push(l, *dev[l])
+    n, n_rm, s, sp = acc.finalize()
+    assert np.all(n + n_rm == n_l)
+    assert s[0, 0] == float(n[0]) and sp[0, 0] == float(n[0])            # P0: exact counts
+    assert not s[1:, 0].any() and not sp[1:, 0].any()                    # P0 differences: exactly 0
+    # counts == number of samples whose transformed fine and coarse fall inside [-1, 1] (bit-exact mask)
+    b = onp.Basis(onp.LEGENDRE, R, dom)
+    for l, (f, c) in enumerate(host):
+        keep = ~np.isnan(onp.transform(b, f))
+        if c is not None:
+            keep &= ~np.isnan(onp.transform(b, c))
+        assert int(keep.sum()) == n[l]
+    # additivity: two halves pushed separately give the same sums
+    acc2 = LevelAccumulator(fn, L)
+    for l in range(L):
+        f, c = dev[l]
+        h = n_l // 2 + 3
+        acc2.push(l, f[:h], None if c is None else c[:h])
+        acc2.push(l, f[h:], None if c is None else c[h:])
+    n2, n_rm2, s2, sp2 = acc2.finalize()
+    assert np.array_equal(n, n2) and np.array_equal(n_rm, n_rm2)
+    rms = np.sqrt(sp / n[:, None]) * n[:, None]
+    assert close(s2, s, rms, 1e-12) and close(sp2, sp, None, 1e-12)
+    # C oracle on a prefix
+    k = 2_000_000
+    accp = LevelAccumulator(fn, L)
+    for l in range(L):
+        f, c = dev[l]
+        accp.push(l, f[:k], None if c is None else c[:k])
+    n3, n_rm3, s3, sp3 = accp.finalize()
+    for l, (f, c) in enumerate(host):
+        nk, nr, so, spo = oracle_c.moments_level(b, f[:k], None if c is None else c[:k])
+        assert nk == n3[l] and nr == n_rm3[l]
+        rms_l = np.sqrt(spo / nk) * nk
+        assert close(s3[l], so, rms_l, 1e-10) and close(sp3[l], spo, None, 1e-10)
