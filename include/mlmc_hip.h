@@ -119,11 +119,11 @@ typedef struct {
 
 /* Minimise F(l) = sum_i mu_i l_i / sigma_i + int exp(-phi(x).l/sigma) dx (simple_distribution.py:259-327)
  * starting from lambda_io (size R1 = number of moments used, <= basis out size); on return lambda_io holds
- * the multipliers (normalisation fix of :86 NOT applied; see moment0), hess_out (may be NULL) the final
- * Hessian [R1 * R1].  prev_lambda/n_prev: Distribution's stabilisation term (distribution.py:358-359), may be NULL/0. */
+ * the multipliers (normalisation fix of :86 NOT applied; see moment0), grad_out / hess_out (may be NULL) the final
+ * gradient [R1] and Hessian [R1 * R1].  prev_lambda/n_prev: Distribution's stabilisation term (distribution.py:358-359), may be NULL/0. */
 int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma, int32_t R1, double a, double bnd_b,
                       const mlmc_maxent_opts *opts, const double *prev_lambda, int32_t n_prev, double *lambda_io,
-                      double *hess_out, mlmc_maxent_info *info);
+                      double *grad_out, double *hess_out, mlmc_maxent_info *info);
 /* SimpleDistribution.density (:96-105): out[i] = exp(clip(-phi(x_i).lambda/sigma, -200, 200)) */
 int mlmc_density_eval(const mlmc_basis *b, const double *lambda, const double *sigma, int32_t R1, const double *x,
                       int64_t n, double *out, int mem_kind);

@@ -1,0 +1,137 @@
+"""MLMC mean / variance estimation of quantities (reference interface: mlmc/quantity/quantity_estimate.py:6-156).
+
+`estimate_mean`, `moments`, `moment`, `covariance`, `mask_nan_samples`, `cache_clear` keep the reference's names,
+arguments, return type (`QuantityMean`) and error behaviour.  What differs is where the work happens: for every
+storage chunk the raw fine / coarse arrays [M, n] go to the MI355X once; the moment functions, the NaN /
+out-of-domain mask, the level differences and the sums of quantity_estimate.py:43-65 are fused into the HIP
+accumulation kernels (mlmc_amd/csrc/moments.hip, cov.hip).  Nothing of shape [M*R, n, 2] or [M*R*R, n, 2] is
+ever materialised.
+"""
+import numpy as np
+
+from . import quantity as qmod
+from . import quantity_types as qt
+from .. import engine
+
+
+def mask_nan_samples(chunk):
+    """Drop samples with a NaN in fine or coarse (reference: quantity_estimate.py:6-14).  Host helper kept for API
+    compatibility; the estimators apply the same rule on the device."""
+    mask = np.any(np.isnan(chunk), axis=0).any(axis=1)
+    return chunk[..., ~mask, :], np.count_nonzero(mask)
+
+
+def cache_clear():
+    qmod.cache_clear()
+
+
+class _MomentsNode(qmod.Quantity):
+    """Quantity node 'moments of x'; evaluated lazily on the device when somebody asks for its samples, fused into
+    the accumulation kernel when it is the root of an estimate."""
+
+    def __init__(self, quantity, moments_fn, at_bottom, qtype):
+        self._moments_fn = moments_fn
+        self._at_bottom = at_bottom
+        super().__init__(quantity_type=qtype, input_quantities=[quantity], operation=self._eval)
+
+    def _eval(self, x):
+        mom = self._moments_fn.eval_all(x)                      # [M, n, 2, R] (device evaluated)
+        mom = mom.transpose((0, 3, 1, 2)) if self._at_bottom else mom.transpose((3, 0, 1, 2))
+        return mom.reshape((int(np.prod(mom.shape[:-2])), mom.shape[-2], mom.shape[-1]))
+
+
+class _CovarianceNode(qmod.Quantity):
+    def __init__(self, quantity, moments_fn, at_bottom, qtype):
+        self._moments_fn = moments_fn
+        self._at_bottom = at_bottom
+        super().__init__(quantity_type=qtype, input_quantities=[quantity], operation=self._eval)
+
+    def _eval(self, x):
+        # The reference materialises [M*R*R, n, 2] doubles here (quantity_estimate.py:131-147).  On this path the
+        # outer products only ever exist inside the MFMA covariance kernel; there is no host fallback.
+        raise NotImplementedError("samples of a covariance quantity are not materialised; use estimate_mean(covariance(...))")
+
+
+def moment(quantity, moments_fn, i=0):
+    """Quantity of the i-th moment function of `quantity` (reference: quantity_estimate.py:83-93)."""
+    return qmod.Quantity(quantity_type=quantity.qtype, input_quantities=[quantity],
+                         operation=lambda x: moments_fn.eval_single_moment(i, value=x))
+
+
+def moments(quantity, moments_fn, mom_at_bottom=True):
+    """Quantity of all moment functions (reference: quantity_estimate.py:96-119)."""
+    if mom_at_bottom:
+        qtype = quantity.qtype.replace_scalar(qt.ArrayType(shape=(moments_fn.size,), qtype=qt.ScalarType()))
+    else:
+        qtype = qt.ArrayType(shape=(moments_fn.size,), qtype=quantity.qtype)
+    return _MomentsNode(quantity, moments_fn, mom_at_bottom, qtype)
+
+
+def covariance(quantity, moments_fn, cov_at_bottom=True):
+    """Quantity of the moment outer products (reference: quantity_estimate.py:122-156)."""
+    shape = (moments_fn.size, moments_fn.size)
+    if cov_at_bottom:
+        qtype = quantity.qtype.replace_scalar(qt.ArrayType(shape=shape, qtype=qt.ScalarType()))
+    else:
+        qtype = qt.ArrayType(shape=shape, qtype=quantity.qtype)
+    return _CovarianceNode(quantity, moments_fn, cov_at_bottom, qtype)
+
+
+def _split_fine_coarse(chunk, level_id):
+    """[M, n, 2|1] -> contiguous fine[M, n], coarse[M, n] | None (level 0 carries no coarse samples)."""
+    fine = np.ascontiguousarray(chunk[:, :, 0], dtype=np.float64)
+    if level_id == 0 or chunk.shape[-1] == 1:
+        return fine, None
+    return fine, np.ascontiguousarray(chunk[:, :, 1], dtype=np.float64)
+
+
+def estimate_mean(quantity, group=None):
+    """MLMC mean estimator (reference: quantity_estimate.py:22-80).
+
+    :param quantity: Quantity
+    :param group: optional torch.distributed process group; when a group (or the default group) with more than one
+                  rank is initialised every rank passes ITS shard of the samples and the level sums are all-reduced.
+    :return: QuantityMean
+    """
+    cache_clear()
+    quantity_vec_size = quantity.size()
+    storage_q = quantity.get_quantity_storage()
+    level_ids = storage_q.level_ids()
+    n_levels = int(np.max(level_ids)) + 1
+
+    if isinstance(quantity, (_MomentsNode, _CovarianceNode)):
+        source = quantity._input_quantities[0]
+        fn = quantity._moments_fn
+        mode = engine.LevelAccumulator.MOMENTS if isinstance(quantity, _MomentsNode) else engine.LevelAccumulator.COV
+        rows_per_comp = fn.size if mode == engine.LevelAccumulator.MOMENTS else fn.size * fn.size
+    else:
+        source, fn, mode, rows_per_comp = quantity, None, engine.LevelAccumulator.MOMENTS, 1
+
+    acc = None
+    n_comp = None
+    for chunk_spec in storage_q.chunks():
+        raw = source.samples(chunk_spec)                         # [M, n, 2|1]
+        if acc is None:
+            n_comp = raw.shape[0]
+            assert n_comp * rows_per_comp == quantity_vec_size
+            acc = engine.LevelAccumulator(fn, n_levels, mode, n_comp=n_comp)
+        if raw.shape[1] == 0:
+            continue
+        fine, coarse = _split_fine_coarse(raw, chunk_spec.level_id)
+        if n_comp == 1:
+            fine, coarse = fine[0], (None if coarse is None else coarse[0])
+        acc.push(chunk_spec.level_id, fine, coarse)
+    if acc is None:
+        raise Exception("All samples were masked")
+    n_samples, n_rm_samples, sums, sums_sq = acc.finalize(group=group)
+    acc.close()
+    if int(np.sum(n_samples)) == 0:
+        raise Exception("All samples were masked")
+
+    if fn is not None and not quantity._at_bottom and n_comp > 1:
+        # device rows are (component, moment...); 'on the surface' wants (moment..., component)
+        sums = sums.reshape(n_levels, n_comp, rows_per_comp).transpose(0, 2, 1).reshape(n_levels, -1)
+        sums_sq = sums_sq.reshape(n_levels, n_comp, rows_per_comp).transpose(0, 2, 1).reshape(n_levels, -1)
+    l_means, l_vars = engine.level_stats(n_samples, sums, sums_sq)
+    return qmod.QuantityMean(quantity.qtype, l_means=l_means, l_vars=l_vars, n_samples=[int(v) for v in n_samples],
+                             n_rm_samples=[int(v) for v in n_rm_samples])

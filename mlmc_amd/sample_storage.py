@@ -1,0 +1,214 @@
+"""Sample storage interface and the in-memory storage (reference interface: mlmc/sample_storage.py:9-338).
+
+Data supplier of the hot path: the estimators only need `chunks()`, `sample_pairs_level()`,
+`get_level_ids()`, `get_n_levels()`, `get_n_collected()`, `get_level_parameters()` and `get_n_ops()`; any object
+with these methods -- including the reference's own `Memory` / `SampleStorageHDF` instances -- can be passed to
+`make_root_quantity` and `Estimate`.
+"""
+import itertools
+from abc import ABCMeta, abstractmethod
+
+import numpy as np
+
+from .quantity.quantity_spec import ChunkSpec
+
+
+class SampleStorage(metaclass=ABCMeta):
+    @abstractmethod
+    def save_samples(self, successful_samples, failed_samples):
+        """Store results of finished samples."""
+
+    @abstractmethod
+    def save_result_format(self, res_spec):
+        """Store the result format (list of QuantitySpec)."""
+
+    @abstractmethod
+    def load_result_format(self):
+        """Return the result format."""
+
+    @abstractmethod
+    def save_global_data(self, result_format, level_parameters=None):
+        """Store result format and level parameters."""
+
+    @abstractmethod
+    def save_scheduled_samples(self, level_id, samples):
+        """Remember ids of scheduled samples."""
+
+    @abstractmethod
+    def load_scheduled_samples(self):
+        """Dict[level_id, list of sample ids]."""
+
+    @abstractmethod
+    def sample_pairs(self):
+        """List over levels of arrays [M, N, 2]."""
+
+    def chunks(self, level_id=None, n_samples=None):
+        """Generator of ChunkSpec over the requested (or all) levels."""
+        assert isinstance(n_samples, (type(None), int)), "n_samples param must be int"
+        level_ids = self.get_level_ids() if level_id is None else [level_id]
+        return itertools.chain(*[self._level_chunks(lid, n_samples) for lid in level_ids])
+
+    @abstractmethod
+    def _level_chunks(self, level_id, n_samples=None):
+        """Generator of ChunkSpec of one level."""
+
+    @abstractmethod
+    def n_finished(self):
+        """Finished samples per level."""
+
+    @abstractmethod
+    def save_n_ops(self, n_ops):
+        """Store cost estimates per level."""
+
+    @abstractmethod
+    def get_n_ops(self):
+        """Cost per sample on every level."""
+
+    @abstractmethod
+    def unfinished_ids(self):
+        """Ids of scheduled but unfinished samples."""
+
+    @abstractmethod
+    def get_level_ids(self):
+        """Level ids."""
+
+    @abstractmethod
+    def get_n_levels(self):
+        """Number of levels."""
+
+    @abstractmethod
+    def get_level_parameters(self):
+        """Level parameters (simulation steps)."""
+
+    @abstractmethod
+    def get_n_collected(self):
+        """Collected samples per level."""
+
+
+class Memory(SampleStorage):
+    """All samples in host RAM, one chunk per level (reference: sample_storage.py:135-338).
+
+    Besides the reference's `save_samples` protocol (lists of (sample_id, (fine, coarse)) per level) whole levels can be
+    handed over as arrays with `set_level_samples`, which is how large synthetic sets are loaded without Python loops.
+    """
+
+    def __init__(self, chunk_size=None):
+        self._failed = {}
+        self._results = {}
+        self._successful_sample_ids = {}
+        self._scheduled = {}
+        self._result_specification = []
+        self._n_ops = {}
+        self._n_finished = {}
+        self._level_parameters = []
+        self._chunk_size = chunk_size     # None = one chunk per level (reference behaviour)
+
+    def save_samples(self, successful_samples, failed_samples):
+        self._save_successful(successful_samples)
+        self._save_failed(failed_samples)
+
+    def save_global_data(self, result_format, level_parameters=None):
+        self.save_result_format(result_format)
+        self._level_parameters = level_parameters
+
+    def set_level_samples(self, level_id, fine, coarse=None, sample_ids=None):
+        """Append a block of samples: fine / coarse arrays [N] or [N, M] (coarse ignored / zero at level 0)."""
+        fine = np.asarray(fine, dtype=np.float64)
+        fine = fine.reshape(fine.shape[0], -1)
+        coarse = np.zeros_like(fine) if coarse is None else np.asarray(coarse, dtype=np.float64).reshape(fine.shape)
+        block = np.stack([fine, coarse], axis=1)                # [N, 2, M]
+        self._append(level_id, block, sample_ids if sample_ids is not None else
+                     ["L{:02d}_S{:07d}".format(level_id, i) for i in range(self._n_finished.get(level_id, 0),
+                                                                          self._n_finished.get(level_id, 0) + len(block))])
+
+    def _append(self, level_id, block, sample_ids):
+        self._successful_sample_ids.setdefault(level_id, []).extend(sample_ids)
+        self._n_finished[level_id] = self._n_finished.get(level_id, 0) + block.shape[0]
+        if level_id in self._results:
+            self._results[level_id] = np.concatenate((self._results[level_id], block), axis=0)
+        else:
+            self._results[level_id] = block
+
+    def _save_successful(self, samples):
+        """samples: Dict[level_id, List[(sample_id, (fine_result, coarse_result))]]"""
+        for level_id, res in samples.items():
+            if len(res) == 0:
+                continue
+            ids = [r[0] for r in res]
+            block = np.array([[np.ravel(r[1][0]), np.ravel(r[1][1])] for r in res], dtype=np.float64)   # [N, 2, M]
+            self._append(level_id, block, ids)
+
+    def _save_failed(self, samples):
+        for level_id, res in samples.items():
+            self._failed.setdefault(level_id, []).extend(res)
+            if level_id not in self._n_finished:
+                self._n_finished[level_id] = 0
+            else:
+                self._n_finished[level_id] += len(res)
+
+    def save_result_format(self, res_spec):
+        self._result_specification = res_spec
+
+    def n_finished(self):
+        out = np.zeros(max(self._n_finished.keys()) + 1)
+        for level_id, n in self._n_finished.items():
+            out[level_id] = n
+        return out
+
+    def load_result_format(self):
+        return self._result_specification
+
+    def save_scheduled_samples(self, level_id, samples):
+        self._scheduled.setdefault(level_id, []).extend(samples)
+
+    def load_scheduled_samples(self):
+        return self._scheduled
+
+    def sample_pairs(self):
+        return [self.sample_pairs_level(ChunkSpec(level_id=level_id)) for level_id in sorted(self.get_level_ids())]
+
+    def _level_chunks(self, level_id, n_samples=None):
+        total = len(self._results[level_id][:n_samples])
+        if self._chunk_size is None or total == 0:
+            yield ChunkSpec(chunk_id=0, chunk_slice=slice(0, total, 1), level_id=level_id)
+            return
+        for cid, start in enumerate(range(0, total, self._chunk_size)):
+            yield ChunkSpec(chunk_id=cid, chunk_slice=slice(start, min(start + self._chunk_size, total), 1), level_id=level_id)
+
+    def sample_pairs_level(self, chunk_spec):
+        """-> ndarray [M, chunk size, 2]; level 0 has no coarse samples: [M, chunk size, 1]."""
+        results = self._results[int(chunk_spec.level_id)]
+        chunk = results if chunk_spec.chunk_slice is None else results[chunk_spec.chunk_slice]
+        if chunk.ndim != 3:
+            chunk = chunk.reshape(chunk.shape[0], chunk.shape[1], -1)
+        if chunk_spec.level_id == 0:
+            chunk = chunk[:, :1, :]
+        return chunk.transpose((2, 0, 1))
+
+    def save_n_ops(self, n_ops):
+        """n_ops: iterable of (level, (time, number of valid samples))"""
+        for level, (time, n_samples) in n_ops:
+            self._n_ops.setdefault(level, 0)
+            if n_samples != 0:
+                self._n_ops[level] += time / n_samples
+
+    def get_n_ops(self):
+        return [self._n_ops[level] for level in sorted(self._n_ops.keys())]
+
+    def unfinished_ids(self):
+        return []
+
+    def get_level_ids(self):
+        return list(self._results.keys())
+
+    def get_n_collected(self):
+        n_collected = [0] * len(self._results)
+        for level_id in self.get_level_ids():
+            n_collected[int(level_id)] = len(self._results[int(level_id)])
+        return n_collected
+
+    def get_n_levels(self):
+        return len(self._results)
+
+    def get_level_parameters(self):
+        return self._level_parameters

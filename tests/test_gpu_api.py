@@ -1,0 +1,259 @@
+"""GPU tests of the drop-in Python API (Moments / Quantity / Estimate / SimpleDistribution) against the golden
+vectors produced by the imported reference (tests/golden, see oracle/gen_golden.py) -- same calls a user of the
+reference makes, `mlmc` replaced by `mlmc_amd`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+from tests.util import close, level_arrays
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mlmc_amd import _lib
+    _lib.init(0)
+    return _lib
+
+
+def _storage(levels, steps, spec, chunk_size=None):
+    from mlmc_amd.sample_storage import Memory
+    st = Memory(chunk_size=chunk_size)
+    st.save_global_data(result_format=spec, level_parameters=[[s] for s in steps])
+    for l, (f, c) in enumerate(levels):
+        st.set_level_samples(l, f.T, None if c is None else c.T)
+    n_ops = [(1 / h) ** 2 * np.log(max(1 / h, 2.0)) for h in steps]
+    st.save_n_ops([(l, (n_ops[l] * len(levels[l][0][0]), len(levels[l][0][0]))) for l in range(len(levels))])
+    return st
+
+
+def _scalar_spec():
+    from mlmc_amd.quantity.quantity_spec import QuantitySpec
+    return [QuantitySpec(name="q", unit="m", shape=(1, 1), times=[1], locations=['0'])]
+
+
+def _vec_spec():
+    from mlmc_amd.quantity.quantity_spec import QuantitySpec
+    return [QuantitySpec(name="q", unit="m", shape=(2, 1), times=[1, 2], locations=['0'])]
+
+
+@pytest.mark.parametrize("tag,chunk", [("L3", None), ("L5", 4096), ("L3nan", 1000), ("L1", None)])
+def test_estimate_api_golden(hip, tag, chunk):
+    from mlmc_amd import Legendre, Monomial
+    from mlmc_amd.estimator import Estimate
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.quantity import quantity_estimate as qe
+    g2 = np.load(os.path.join(GOLDEN, "G2_estimate_mean.npz"))
+    dom = tuple(g2["domain"])
+    N, steps, nan_every = g2[f"{tag}_N"], g2[f"{tag}_steps"], int(g2[f"{tag}_nan_every"])
+    levels = level_arrays(N, steps, 1, nan_every)
+    st = _storage(levels, steps, _scalar_spec(), chunk)
+    root = make_root_quantity(st, _scalar_spec())
+    q = root['q'][1]['0'][0, 0]
+    for R in (5, 32, 64):
+        fn = Legendre(R, dom)
+        est = Estimate(q, st, fn)
+        means, vars_ = est.estimate_moments(fn)
+        key = f"{tag}_leg{R}_b1"
+        assert means.shape == g2[key + "_mean"].shape
+        assert means[0] == 1 and vars_[0] == 0
+        assert close(means, g2[key + "_mean"], 1.0, TOL) and close(vars_, g2[key + "_var"], None, TOL)
+        r = qe.estimate_mean(qe.moments(q, fn, mom_at_bottom=False))
+        assert np.array_equal(r.n_samples, g2[f"{tag}_leg{R}_b0_n"]) and np.array_equal(r.n_rm_samples, g2[f"{tag}_leg{R}_b0_n_rm"])
+        assert r.l_means.shape == g2[f"{tag}_leg{R}_b0_l_means"].shape
+        assert close(r.l_vars, g2[f"{tag}_leg{R}_b0_l_vars"], None, TOL)
+        l_vars, n_s = est.estimate_diff_vars(fn)
+        assert close(l_vars, g2[key + "_l_vars"], None, TOL) and np.array_equal(n_s, g2[key + "_n"])
+    means, vars_ = Estimate(q, st, Monomial(6, dom)).estimate_moments()
+    assert close(means, g2[f"{tag}_mono6_mean"], 1.0, TOL) and close(vars_, g2[f"{tag}_mono6_var"], None, TOL)
+    r = qe.estimate_mean(q)                                            # plain quantity
+    assert close(r.mean, g2[f"{tag}_plain_mean"], 1.0, TOL) and close(r.var, g2[f"{tag}_plain_var"], None, TOL)
+    assert np.array_equal(r.n_rm_samples, g2[f"{tag}_plain_n_rm"])
+    r = qe.estimate_mean(qe.moment(q, Legendre(8, dom), 3))             # single moment node
+    assert close(r.mean, g2[f"{tag}_moment3_mean"], 1.0, TOL) and close(r.var, g2[f"{tag}_moment3_var"], None, TOL)
+    # quantity algebra in front of the estimator: linearity of the mean
+    r2 = qe.estimate_mean(2.0 * q + 1.0)
+    r1 = qe.estimate_mean(q)
+    assert close(r2.mean, 2.0 * r1.mean + 1.0, 1.0, 1e-12)
+
+
+def test_estimate_api_vector_quantity(hip):
+    """M = 4 quantity: moments at the bottom and on the surface, sub-selection of the result"""
+    from mlmc_amd import Legendre
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.quantity import quantity_estimate as qe
+    g2 = np.load(os.path.join(GOLDEN, "G2_estimate_mean.npz"))
+    tag = "L3M4"
+    dom = tuple(g2["domain"])
+    levels = level_arrays(g2[f"{tag}_N"], g2[f"{tag}_steps"], 4, int(g2[f"{tag}_nan_every"]))
+    st = _storage(levels, g2[f"{tag}_steps"], _vec_spec())
+    q = make_root_quantity(st, _vec_spec())['q']
+    fn = Legendre(5, dom)
+    for bottom in (True, False):
+        r = qe.estimate_mean(qe.moments(q, fn, mom_at_bottom=bottom))
+        key = f"{tag}_leg5_b{int(bottom)}"
+        assert r.mean.shape == g2[key + "_mean"].shape
+        assert np.array_equal(r.n_samples, g2[key + "_n"]) and np.array_equal(r.n_rm_samples, g2[key + "_n_rm"])
+        assert close(r.mean, g2[key + "_mean"], 1.0, TOL) and close(r.var, g2[key + "_var"], None, TOL)
+        assert close(r.l_means, g2[key + "_l_means"], 1.0, TOL) and close(r.l_vars, g2[key + "_l_vars"], None, TOL)
+    # indexing a QuantityMean and a quantity
+    # (the NaN mask of a sub-selection differs from that of the whole vector quantity, so only shapes are comparable)
+    r = qe.estimate_mean(qe.moments(q[1]['0'], fn))
+    full = qe.estimate_mean(qe.moments(q, fn))
+    assert r.mean.shape == full[1]['0'].mean.shape == (2, 1, 5)
+    assert np.all(r.n_samples >= full.n_samples)
+
+
+def test_covariance_regression_allocation(hip):
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate, estimate_n_samples_for_target_variance, determine_level_parameters, \
+        determine_n_samples, calc_level_params
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    g2 = np.load(os.path.join(GOLDEN, "G2_estimate_mean.npz"))
+    g3 = np.load(os.path.join(GOLDEN, "G3_cov.npz"))
+    with open(os.path.join(GOLDEN, "G4_alloc.json")) as f:
+        g4 = json.load(f)
+    dom = tuple(g2["domain"])
+    for tag in ("L3", "L5"):
+        N, steps = g2[f"{tag}_N"], g2[f"{tag}_steps"]
+        levels = level_arrays(N, steps, 1, 0)
+        st = _storage(levels, steps, _scalar_spec())
+        q = make_root_quantity(st, _scalar_spec())['q'][1]['0'][0, 0]
+        for R in (5, 32):
+            d = g4[f"{tag}_R{R}"]
+            fn = Legendre(R, dom)
+            est = Estimate(q, st, fn)
+            reg_vars, n_ops = est.estimate_diff_vars_regression(list(N), fn)
+            assert np.allclose(n_ops, d["n_ops"], rtol=1e-12)
+            assert close(reg_vars, np.array(d["reg_vars"]), None, 1e-9)
+            n_est = estimate_n_samples_for_target_variance(1e-6, reg_vars, n_ops, n_levels=len(N))
+            assert np.array_equal(n_est, d["n_estimated"]), (n_est, d["n_estimated"])     # bit-exact integer allocation
+            raw, _ = est.estimate_diff_vars(fn)
+            n_est = estimate_n_samples_for_target_variance(1e-5, raw, n_ops, n_levels=len(N))
+            assert np.array_equal(n_est, d["n_estimated_raw"])
+        if tag == "L3":
+            for R in (8, 16):
+                Ncov = g3[f"{tag}_cov{R}_Ncov"]
+                lv = [(f[:, :k], None if c is None else c[:, :k]) for (f, c), k in zip(levels, Ncov)]
+                stc = _storage(lv, steps, _scalar_spec(), chunk_size=700)
+                qc = make_root_quantity(stc, _scalar_spec())['q'][1]['0'][0, 0]
+                cov, cov_var = Estimate(qc, stc, Legendre(R, dom)).estimate_covariance()
+                assert cov.shape == (R, R)
+                assert close(cov, g3[f"{tag}_cov{R}_mean"], 1.0, TOL) and close(cov_var, g3[f"{tag}_cov{R}_var"], None, TOL)
+    assert determine_level_parameters(5, [0.5, 0.01]) == g4["level_params_5"]
+    assert calc_level_params([0.5, 0.01], 1) == g4["level_params_1"]
+    assert determine_n_samples(5).tolist() == g4["determine_n_samples_5"]
+    assert determine_n_samples(4, [1000, 10]).tolist() == g4["determine_n_samples_4_1000_10"]
+
+
+def test_orthogonal_moments_and_maxent(hip):
+    from mlmc_amd import Legendre
+    from mlmc_amd.tool import simple_distribution as sd
+    g5 = np.load(os.path.join(GOLDEN, "G5_ortho.npz"))
+    g6 = np.load(os.path.join(GOLDEN, "G6_maxent.npz"))
+    for name in ("norm12", "norm110", "lognorm"):
+        for R in (7, 21, 41):
+            key = f"{name}_R{R}"
+            dom = tuple(g5[key + "_domain"])
+            base = Legendre(R, dom)
+            cov = g5[key + "_cov"]
+            for tol in (1e-4, 0.0, 1e-10):
+                ortho, (ev, thr, L) = sd.construct_ortogonal_moments(base, cov, tol)
+                tk = key + "_tol{:g}".format(tol)
+                assert thr == int(g5[tk + "_threshold"])
+                assert np.allclose(ev, g5[tk + "_eval"], rtol=1e-9, atol=1e-13) and np.allclose(L, g5[tk + "_L"], rtol=1e-7, atol=1e-9)
+            # semi-exact covariance by the device-evaluated basis reproduces the reference's (QUADPACK based) one
+            import scipy.stats as stats
+            distr = dict(norm12=stats.norm(loc=1, scale=2), norm110=stats.norm(loc=1, scale=10),
+                         lognorm=stats.lognorm(scale=np.exp(1), s=1))[name]
+            nc = distr.cdf(dom[1]) - distr.cdf(dom[0])
+            pdf = lambda x: distr.pdf(x) / nc
+            assert np.allclose(sd.compute_semiexact_cov(base, pdf), cov, rtol=1e-8, atol=1e-10)
+            # max-entropy solve from the reference's moment data, orthogonal basis of the reference
+            ortho = __import__("mlmc_amd").TransformedMoments(base, g6[key + "_L"])
+            d = sd.SimpleDistribution(ortho, g6[key + "_moment_data"].copy(), domain=dom)
+            res = d.estimate_density_minimize(tol=1e-8)
+            assert res.success and res.fun_norm < 1e-8 and res.nit >= 1
+            assert len(res.eigvals) == ortho.size and np.all(res.eigvals > 0)
+            # converged multipliers / density / cdf: the reference stops at gradient 1e-9 on a quadrature with 1e-10
+            # tolerance, so agreement is limited by ITS accuracy (SURVEY section 7 'QUADPACK dependence')
+            ref_mult = g6[key + "_sd_multipliers"]
+            assert np.allclose(d.multipliers, ref_mult, rtol=2e-5, atol=2e-6), np.max(np.abs(d.multipliers - ref_mult))
+            xg = g6[key + "_xgrid"]
+            assert np.allclose(d.density(xg), g6[key + "_sd_density"], rtol=1e-5, atol=1e-8)
+            assert np.allclose(d.cdf(xg[::8]), g6[key + "_sd_cdf"], rtol=1e-5, atol=1e-7)
+            # moments of the reconstructed density reproduce the prescribed ones (what `tol` promises)
+            mom = sd.compute_semiexact_moments(ortho, d.density)
+            assert np.linalg.norm(mom - g6[key + "_moment_data"][:, 0]) < 1e-6
+
+
+def test_construct_density_end_to_end(hip):
+    """Estimate.construct_density: covariance pass -> orthogonal moments -> moments pass -> max-entropy solve, against the
+    same chain evaluated by the oracle (SciPy trust-ncg restatement of the reference)."""
+    import scipy.stats as stats
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    dom = tuple(stats.norm().ppf([1e-3, 1 - 1e-3]))
+    steps = [0.5, 0.07, 0.01]
+    levels = level_arrays([40000, 6000, 1500], steps, 1, 0)
+    st = _storage(levels, steps, _scalar_spec())
+    q = make_root_quantity(st, _scalar_spec())['q'][1]['0'][0, 0]
+    R = 13
+    est = Estimate(q, st, Legendre(R, dom))
+    distr_obj, info, result, moments_obj = est.construct_density(tol=1e-8, orth_moments_tol=1e-4)
+    assert result.success and moments_obj.size <= R
+    # oracle chain on the same samples
+    from tests.util import to_chunks
+    b = onp.Basis(onp.LEGENDRE, R, dom)
+    cov = onp.estimate_mean(to_chunks(levels), lambda x: onp.covariance_rows(b, x)).mean.reshape(R, R)
+    L, ev, thr = onp.construct_orthogonal_matrix(cov, 1e-4)
+    assert thr == info[1] and np.allclose(L, info[2], rtol=1e-6, atol=1e-8)
+    bt = onp.Basis(onp.LEGENDRE, R, dom, matrix=L)
+    mom = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(bt, x)).mean
+    o = onp.MaxEntOracle(bt, np.stack([mom, np.ones_like(mom)], axis=1), dom)
+    ores = o.solve(tol=1e-8, max_it=50)
+    xg = np.linspace(dom[0], dom[1], 201)
+    assert np.allclose(distr_obj.multipliers, o.multipliers, rtol=1e-4, atol=1e-5)
+    assert np.allclose(distr_obj.density(xg), o.density(xg), rtol=1e-4, atol=1e-7)
+    # vector quantity -> NotImplementedError as in the reference (estimator.py:308-309)
+    with pytest.raises(NotImplementedError):
+        Estimate(make_root_quantity(st, _scalar_spec())['q'], st, Legendre(R, dom)).construct_density()
+
+
+def test_all_samples_masked_raises(hip):
+    from mlmc_amd import Legendre
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.quantity import quantity_estimate as qe
+    levels = [(np.full((1, 50), 100.0), None), (np.full((1, 20), 100.0), np.full((1, 20), 100.0))]
+    st = _storage(levels, [0.1, 0.01], _scalar_spec())
+    q = make_root_quantity(st, _scalar_spec())['q'][1]['0'][0, 0]
+    with pytest.raises(Exception, match="All samples were masked"):
+        qe.estimate_mean(qe.moments(q, Legendre(4, (-1.0, 1.0))))
+
+
+def test_old_distribution_solver(hip):
+    """tool/distribution.py staged solver: converges and reproduces the prescribed moments; the reference's
+    multipliers (G6 *_old_*) are matched loosely -- its penalty terms make the optimum depend on solver details."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.tool import distribution as dd, simple_distribution as sd
+    g6 = np.load(os.path.join(GOLDEN, "G6_maxent.npz"))
+    for name in ("norm12", "lognorm"):
+        for R in (5, 11):
+            key = f"{name}_old_R{R}"
+            dom = tuple(g6[key + "_domain"])
+            base = Legendre(R, dom)
+            d = dd.Distribution(base, g6[key + "_moment_data"].copy(), domain=dom, force_decay=(True, True))
+            res = d.estimate_density_minimize(tol=1e-6, reg_param=0.0)
+            assert res.success, (key, res.fun_norm)
+            xg = g6[key + "_xgrid"]
+            ref = g6[key + "_density"]
+            got = d.density(xg)
+            assert np.all(np.isfinite(got))
+            assert np.max(np.abs(got - ref)) < 2e-2 * np.max(ref), (key, np.max(np.abs(got - ref)), np.max(ref))

@@ -281,7 +281,8 @@ def test_edge_cases(hip):
     acc.reset()
     acc.push(0, x)
     n, n_rm, s, sp = acc.finalize()
-    assert n[0] == 4 and n_rm[0] == 5
+    keep = ~np.isnan(onp.transform(onp.Basis(onp.LEGENDRE, 7, dom), x))     # NumPy rounding decides (1 + ulp maps to exactly 1.0)
+    assert n[0] == int(keep.sum()) == 5 and n_rm[0] == 4
     # chunked pushes == one push (additivity), finalize idempotent
     rng = np.random.default_rng(0)
     f = rng.uniform(-1.1, 1.1, 30001)
