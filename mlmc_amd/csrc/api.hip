@@ -128,6 +128,7 @@ int mlmc_basis_create(const mlmc_basis_desc *d, mlmc_basis **out) {
     if (d->kind < MLMC_LEGENDRE || d->kind > MLMC_IDENTITY) return fail("mlmc_basis_create: unknown kind");
     if (d->kind == MLMC_IDENTITY && d->size != 1) return fail("mlmc_basis_create: IDENTITY has size 1");
     if (d->out_size < 0 || (d->out_size > 0 && !d->matrix)) return fail("mlmc_basis_create: matrix missing");
+    if (d->kind == MLMC_LEGENDRE && d->size > 512) return fail("mlmc_basis_create: at most 512 Legendre moments");
     mlmc_basis *b = new (std::nothrow) mlmc_basis();
     if (!b) return fail("out of memory");
     b->p.kind = d->kind;
@@ -225,14 +226,19 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
         a->int_width = 3 * (int64_t)a->RP * a->RP;
     }
     const size_t tot = (size_t)n_levels * n_comp * a->int_width;
-    if (hipMalloc(&a->d_totals, sizeof(double) * tot) != hipSuccess ||
-        hipMalloc(&a->d_counts, sizeof(int64_t) * 2 * n_levels) != hipSuccess ||
-        hipMalloc(&a->d_out_s, sizeof(double) * (size_t)n_levels * a->K) != hipSuccess ||
-        hipMalloc(&a->d_out_sp, sizeof(double) * (size_t)n_levels * a->K) != hipSuccess ||
-        hipMalloc(&a->d_out_n, sizeof(int64_t) * 2 * n_levels) != hipSuccess) {
+    a->state_bytes = sizeof(double) * tot + sizeof(int64_t) * 2 * n_levels + 64;
+    a->out_bytes = sizeof(int64_t) * 2 * n_levels + 2 * sizeof(double) * (size_t)n_levels * a->K;
+    if (hipMalloc(&a->d_state, a->state_bytes) != hipSuccess || hipMalloc(&a->d_out, a->out_bytes) != hipSuccess ||
+        hipHostMalloc(&a->h_out, a->out_bytes, hipHostMallocDefault) != hipSuccess) {
         mlmc_accum_destroy(a);
-        return fail("mlmc_accum_create: hipMalloc failed");
+        return fail("mlmc_accum_create: device / pinned allocation failed");
     }
+    a->d_totals = (double *)a->d_state;
+    a->d_counts = (int64_t *)(a->d_totals + tot);
+    a->d_ticket = (unsigned *)(a->d_counts + 2 * (size_t)n_levels);
+    a->d_out_n = (int64_t *)a->d_out;
+    a->d_out_s = (double *)(a->d_out_n + 2 * (size_t)n_levels);
+    a->d_out_sp = a->d_out_s + (size_t)n_levels * a->K;
     *out = a;
     return mlmc_accum_reset(a);
 }
@@ -241,8 +247,7 @@ int mlmc_accum_reset(mlmc_accum *a) {
     if (need_runtime()) return 1;
     if (!a) return fail("mlmc_accum_reset: null argument");
     hipStream_t st = rt().stream;
-    MLMC_HIP_CHECK(hipMemsetAsync(a->d_totals, 0, sizeof(double) * (size_t)a->n_levels * a->n_comp * a->int_width, st));
-    MLMC_HIP_CHECK(hipMemsetAsync(a->d_counts, 0, sizeof(int64_t) * 2 * a->n_levels, st));
+    MLMC_HIP_CHECK(hipMemsetAsync(a->d_state, 0, a->state_bytes, st));
     a->ev_used = 0;
     a->ms_total = 0;
     a->launches = 0;
@@ -253,10 +258,10 @@ int mlmc_accum_reset(mlmc_accum *a) {
 void mlmc_accum_destroy(mlmc_accum *a) {
     if (!a) return;
     if (rt().ready) (void)hipStreamSynchronize(rt().stream);
-    void *ptrs[] = {a->d_totals, a->d_counts, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c,
-                    a->d_mask, a->d_out_s, a->d_out_sp, a->d_out_n};
+    void *ptrs[] = {a->d_state, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c, a->d_mask, a->d_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (a->h_out) (void)hipHostFree(a->h_out);
     for (hipEvent_t e : a->ev) (void)hipEventDestroy(e);
     delete a;
 }
@@ -327,20 +332,23 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
     int rc = (a->mode == MLMC_MODE_MOMENTS) ? launch_moments_finalize(a) : launch_cov_finalize(a);
     if (rc) return rc;
     const int L = a->n_levels;
-    const hipMemcpyKind kind = (mem_kind == MLMC_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    // counts are stored interleaved (kept, removed) per level
-    std::vector<int64_t> cnt(2 * (size_t)L);
-    MLMC_HIP_CHECK(hipMemcpyAsync(cnt.data(), a->d_counts, sizeof(int64_t) * 2 * L, hipMemcpyDeviceToHost, st));
-    MLMC_HIP_CHECK(hipMemcpyAsync(s, a->d_out_s, sizeof(double) * (size_t)L * a->K, kind, st));
-    MLMC_HIP_CHECK(hipMemcpyAsync(sp, a->d_out_sp, sizeof(double) * (size_t)L * a->K, kind, st));
-    MLMC_HIP_CHECK(hipStreamSynchronize(st));
+    const size_t nk = (size_t)L * a->K;
     if (mem_kind == MLMC_DEVICE) {
-        std::vector<int64_t> k(L), r(L);
-        for (int l = 0; l < L; ++l) { k[l] = cnt[2 * l]; r[l] = cnt[2 * l + 1]; }
-        MLMC_HIP_CHECK(hipMemcpy(n, k.data(), sizeof(int64_t) * L, hipMemcpyHostToDevice));
-        MLMC_HIP_CHECK(hipMemcpy(n_rm, r.data(), sizeof(int64_t) * L, hipMemcpyHostToDevice));
+        MLMC_HIP_CHECK(hipMemcpyAsync(n, a->d_out_n, sizeof(int64_t) * L, hipMemcpyDeviceToDevice, st));
+        MLMC_HIP_CHECK(hipMemcpyAsync(n_rm, a->d_out_n + L, sizeof(int64_t) * L, hipMemcpyDeviceToDevice, st));
+        MLMC_HIP_CHECK(hipMemcpyAsync(s, a->d_out_s, sizeof(double) * nk, hipMemcpyDeviceToDevice, st));
+        MLMC_HIP_CHECK(hipMemcpyAsync(sp, a->d_out_sp, sizeof(double) * nk, hipMemcpyDeviceToDevice, st));
+        MLMC_HIP_CHECK(hipStreamSynchronize(st));
     } else {
-        for (int l = 0; l < L; ++l) { n[l] = cnt[2 * l]; n_rm[l] = cnt[2 * l + 1]; }
+        // one packed copy into the pinned mirror, then plain host copies into the caller's arrays
+        MLMC_HIP_CHECK(hipMemcpyAsync(a->h_out, a->d_out, a->out_bytes, hipMemcpyDeviceToHost, st));
+        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        const int64_t *hn = (const int64_t *)a->h_out;
+        const double *hs = (const double *)(hn + 2 * (size_t)L);
+        std::memcpy(n, hn, sizeof(int64_t) * L);
+        std::memcpy(n_rm, hn + L, sizeof(int64_t) * L);
+        std::memcpy(s, hs, sizeof(double) * nk);
+        std::memcpy(sp, hs + nk, sizeof(double) * nk);
     }
     return timing_collect(a);
 }

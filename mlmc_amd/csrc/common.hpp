@@ -62,14 +62,20 @@ struct mlmc_accum {
     // internal totals per (level, component): MOMENTS: [2][R] (sum d, sum d^2) (+ [R][R] diff Gram if transform)
     //                                         COV: [3][RP][RP] (G0, G1, G2)
     int64_t int_width = 0;        // doubles per (level, comp)
+    void *d_state = nullptr;      // one allocation: totals | counts | ticket (reset = one memset)
+    size_t state_bytes = 0;
     double *d_totals = nullptr;   // [n_levels][n_comp][int_width]
     int64_t *d_counts = nullptr;  // [n_levels][2]  (kept, removed)
+    unsigned *d_ticket = nullptr; // arrival counter of the in-kernel grid reduction
     // scratch
     double *d_partials = nullptr; size_t partials_cap = 0;
     int64_t *d_pcounts = nullptr; size_t pcounts_cap = 0;
     double *d_stage_f = nullptr, *d_stage_c = nullptr; size_t stage_cap = 0;
     uint8_t *d_mask = nullptr; size_t mask_cap = 0;
-    double *d_out_s = nullptr, *d_out_sp = nullptr; int64_t *d_out_n = nullptr;   // finalize outputs [L*K], [L*2]
+    void *d_out = nullptr;        // finalize outputs, one allocation: n[L] | n_rm[L] | s[L*K] | sp[L*K]
+    size_t out_bytes = 0;
+    void *h_out = nullptr;        // pinned host mirror of d_out
+    double *d_out_s = nullptr, *d_out_sp = nullptr; int64_t *d_out_n = nullptr;
     // timing
     std::vector<hipEvent_t> ev;   // pairs (start, stop)
     size_t ev_used = 0;

@@ -25,6 +25,19 @@ __device__ __forceinline__ double transform_value(const BasisParams &bp, double 
     return t;
 }
 
+// Monic Legendre recurrence coefficients g_i = (i-1)^2 / ((2i-1)(2i-3)) as a compile-time table: in the fully
+// unrolled accumulation kernels every index is a constant, so the values become instruction operands
+// (s_mov literals) instead of scalar loads that the wave would have to wait for inside the hot loop.
+constexpr int LEGENDRE_MAX_TERMS = 512;
+struct LegendreG {
+    double v[LEGENDRE_MAX_TERMS];
+    constexpr LegendreG() : v() {
+        for (int i = 0; i < LEGENDRE_MAX_TERMS; ++i)
+            v[i] = i < 2 ? 0.0 : (double)((long long)(i - 1) * (i - 1)) / (double)((long long)(2 * i - 1) * (2 * i - 3));
+    }
+};
+__device__ constexpr LegendreG kLegendreG = LegendreG();
+
 // Sequential generator of basis terms 0, 1, 2, ... for one value.  `w` (1 = kept, 0 = masked) is
 // folded into the seed so that a masked value yields exactly 0 in every term.
 //
@@ -51,7 +64,7 @@ struct TermGen {
         if (KIND == MLMC_LEGENDRE) {
             double q;
             if (i == 1) q = x * p1;
-            else q = __builtin_fma(x, p1, -(coef[i] * p2));
+            else q = __builtin_fma(x, p1, -(kLegendreG.v[i] * p2));
             p2 = p1;
             p1 = q;
             return q;

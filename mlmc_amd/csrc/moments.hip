@@ -10,6 +10,8 @@
 // recurrences for fine and coarse kept in registers, per-lane fp64 accumulators for sum(d) and sum(d^2),
 // wave shuffles + LDS for the block partial, and a fixed-order second kernel for the grid reduction
 // (bitwise reproducible run to run).
+#include <cstdlib>
+
 #include "device_basis.hpp"
 
 namespace mlmc {
@@ -117,20 +119,23 @@ int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64
 
 // ------------------------------------------------------------------------------------------
 // The accumulation kernel.
-//   RT    : accumulators per lane for sum(d) and sum(d^2) (terms [t0, t0 + RT) of this pass)
+//   RT    : accumulators per lane for sum(d) and sum(d^2): terms [t0, t0 + RT) of this pass (terms >= R, if any,
+//           are computed and discarded, so the loop body is one branch-free basic block)
 //   PAIR  : level >= 1 (fine and coarse) / level 0 (fine only)
-// Each lane walks the samples with a grid stride, two samples per trip (four independent recurrences
-// when PAIR) so that the fp64 pipe always has independent work; the next trip's loads are issued before
-// the current trip's arithmetic.
+//   FIRST : t0 == 0 (every term index is a compile-time constant)
+// Each lane walks the samples with a grid stride, two samples per trip (four independent recurrences when
+// PAIR) so that the fp64 pipe always has independent work; the next trip's loads are issued before the
+// current trip's arithmetic.  Per pair and term: mul + fma (fine), mul + fma (coarse), sub, add, fma = 7 fp64
+// instructions (the reference's NumPy path does 14 R flops per pair in ~10 R array passes).
 // ------------------------------------------------------------------------------------------
 template <int KIND, int RT, bool PAIR, bool FIRST>
 __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, const double *__restrict__ coef,
                                                               const double *__restrict__ fine,
                                                               const double *__restrict__ coarse,
-                                                              const uint8_t *__restrict__ mask, int64_t n, int t0_arg, int R,
+                                                              const uint8_t *__restrict__ mask, int64_t n, int t0_arg,
                                                               double *__restrict__ partials,
                                                               int64_t *__restrict__ pcounts) {
-    const int t0 = FIRST ? 0 : t0_arg;   // first pass: every term index is a compile-time constant
+    const int t0 = FIRST ? 0 : t0_arg;
     double s[RT], sp[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
@@ -138,7 +143,6 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, c
 
     const int64_t T = (int64_t)gridDim.x * ACC_THREADS;
     const int64_t gtid = (int64_t)blockIdx.x * ACC_THREADS + threadIdx.x;
-    const int n_terms = R - t0;   // terms of this pass actually wanted (<= RT)
 
     int64_t i0 = gtid, i1 = gtid + T;
     double f0 = 0, f1 = 0, c0 = 0, c1 = 0;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, c
     if (i1 < n) { f1 = fine[i1]; if (PAIR) c1 = coarse[i1]; if (mask) m1 = mask[i1]; }
 
     while (i0 < n) {
-        const bool v0 = true, v1 = i1 < n;
+        const bool v1 = i1 < n;
         const double xf0 = f0, xf1 = f1, xc0 = c0, xc1 = c1;
         const uint8_t mm0 = m0, mm1 = m1;
         // prefetch the next trip
@@ -156,14 +160,14 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, c
         if (j1 < n) { f1 = fine[j1]; if (PAIR) c1 = coarse[j1]; if (mask) m1 = mask[j1]; }
 
         bool kf0, kf1, kc0 = true, kc1 = true;
-        double tf0 = transform_value(bp, xf0, kf0);
-        double tf1 = transform_value(bp, xf1, kf1);
+        const double tf0 = transform_value(bp, xf0, kf0);
+        const double tf1 = transform_value(bp, xf1, kf1);
         double tc0 = 0, tc1 = 0;
         if (PAIR) { tc0 = transform_value(bp, xc0, kc0); tc1 = transform_value(bp, xc1, kc1); }
-        bool k0 = v0 && kf0 && kc0 && (mm0 != 0);
-        bool k1 = v1 && kf1 && kc1 && (mm1 != 0);
+        const bool k0 = kf0 && kc0 && (mm0 != 0);
+        const bool k1 = v1 && kf1 && kc1 && (mm1 != 0);
         n_keep += (int)k0 + (int)k1;
-        n_rm += (int)(v0 && !k0) + (int)(v1 && !k1);
+        n_rm += (int)(!k0) + (int)(v1 && !k1);
         const double w0 = k0 ? 1.0 : 0.0, w1 = k1 ? 1.0 : 0.0;
 
         TermGen<KIND> gf0, gf1, gc0, gc1;
@@ -171,171 +175,208 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, c
         gf1.init(k1 ? tf1 : 0.0, w1);
         if (PAIR) { gc0.init(k0 ? tc0 : 0.0, w0); gc1.init(k1 ? tc1 : 0.0, w1); }
 
-        // terms below t0 (later passes of R > 64): advance the recurrences without accumulating
-        for (int i = 0; i < t0; ++i) {
-            gf0.next(i, coef); gf1.next(i, coef);
-            if (PAIR) { gc0.next(i, coef); gc1.next(i, coef); }
+        if (!FIRST) {   // later passes of R > 64: advance the recurrences without accumulating
+            for (int i = 0; i < t0; ++i) {
+                gf0.next(i, coef); gf1.next(i, coef);
+                if (PAIR) { gc0.next(i, coef); gc1.next(i, coef); }
+            }
         }
 #pragma unroll
-        for (int ib = 0; ib < RT; ib += 4) {
-            if (ib < n_terms) {   // wave-uniform guard, 4 terms at a time
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int i = ib + ii;
-                    double d0 = gf0.next(t0 + i, coef);
-                    double d1 = gf1.next(t0 + i, coef);
-                    if (PAIR) { d0 -= gc0.next(t0 + i, coef); d1 -= gc1.next(t0 + i, coef); }
-                    s[i] += d0;
-                    sp[i] = __builtin_fma(d0, d0, sp[i]);
-                    s[i] += d1;
-                    sp[i] = __builtin_fma(d1, d1, sp[i]);
-                }
-            }
+        for (int i = 0; i < RT; ++i) {
+            double d0 = gf0.next(t0 + i, coef);
+            double d1 = gf1.next(t0 + i, coef);
+            if (PAIR) { d0 -= gc0.next(t0 + i, coef); d1 -= gc1.next(t0 + i, coef); }
+            s[i] += d0;
+            sp[i] = __builtin_fma(d0, d0, sp[i]);
+            s[i] += d1;
+            sp[i] = __builtin_fma(d1, d1, sp[i]);
         }
         i0 = j0;
         i1 = j1;
     }
 
-    // ---- block partial: wave shuffles, then the 4 waves through LDS in a fixed order ----
-    __shared__ double lds[4][2 * RT];
+    // ---- block partial: the four waves add their lanes' accumulators into one LDS image [value][lane] in a
+    // fixed order, then one thread per value sums the 64 lanes (row stride 65: conflict-free both ways) ----
+    __shared__ double red[2 * RT][WAVE + 1];
     __shared__ int ldc[4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            if (w == 0) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        double a = wave_sum(s[i]);
-        double b = wave_sum(sp[i]);
-        if (lane == 0) { lds[wave][i] = a; lds[wave][RT + i] = b; }
+                for (int i = 0; i < RT; ++i) { red[i][lane] = s[i]; red[RT + i][lane] = sp[i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RT; ++i) { red[i][lane] += s[i]; red[RT + i][lane] += sp[i]; }
+            }
+        }
+        __syncthreads();
     }
     n_keep = wave_sum_i(n_keep);
     n_rm = wave_sum_i(n_rm);
     if (lane == 0) { ldc[wave][0] = n_keep; ldc[wave][1] = n_rm; }
     __syncthreads();
-    if (threadIdx.x < 2 * RT) {
-        const int j = threadIdx.x;
-        double v = ((lds[0][j] + lds[1][j]) + lds[2][j]) + lds[3][j];
+    for (int j = threadIdx.x; j < 2 * RT; j += ACC_THREADS) {
+        double v = 0.0;
+#pragma unroll 8
+        for (int l = 0; l < WAVE; ++l) v += red[j][l];
         partials[(int64_t)blockIdx.x * (2 * RT) + j] = v;
     }
-    if (threadIdx.x < 2 && pcounts) {
+    if (threadIdx.x < 2) {
         int v = ldc[0][threadIdx.x] + ldc[1][threadIdx.x] + ldc[2][threadIdx.x] + ldc[3][threadIdx.x];
         pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = v;
     }
 }
 
-// totals[col] += sum over blocks of partials[block][col], fixed order: 64 columns x 16 row groups per block.
-__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials, int nblocks, int width,
-                                                         double *__restrict__ totals, int col_map_rt, int t0,
-                                                         int int_R) {
+// Grid reduction of one accumulation launch, one 1024-thread block, fixed order (bitwise reproducible):
+//   totals[which][t0 + i] += sum_b partials[b][which * RT + i],   counts += sum_b pcounts[b]
+// 16 row groups x 64 columns, every thread keeps its <= 32 row loads in flight.  (Measured alternative: letting the
+// last-arriving block of the accumulation kernel do this behind an agent-scope release / acquire costs ~13 us of
+// kernel tail per launch -- every block's L2 write-back -- against ~4 us for this launch.)
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials,
+                                                         const int64_t *__restrict__ pcounts, int nblocks, int width, int RT,
+                                                         int t0, int int_R, int do_count, double *__restrict__ totals,
+                                                         int64_t *__restrict__ counts) {
     __shared__ double lds[16][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + c;
-    double acc = 0.0;
-    if (col < width)
-        for (int b = g; b < nblocks; b += 16) acc += partials[(int64_t)b * width + col];
-    lds[g][c] = acc;
-    __syncthreads();
-    if (g == 0 && col < width) {
-        double v = 0.0;
+    for (int c0 = 0; c0 < width; c0 += 64) {
+        const int col = c0 + c;
+        double acc = 0.0;
+        if (col < width) {
+            const double *__restrict__ pc = partials + col;
+#pragma unroll 8
+            for (int b = g; b < nblocks; b += 16) acc += pc[(int64_t)b * width];
+        }
+        __syncthreads();
+        lds[g][c] = acc;
+        __syncthreads();
+        if (g == 0 && col < width) {
+            double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v += lds[k][c];
-        // map pass-local column (s: [0, RT), sp: [RT, 2 RT)) to the totals layout [2][int_R]
-        int which = col / col_map_rt, i = col % col_map_rt;
-        int term = t0 + i;
-        if (term < int_R) totals[(int64_t)which * int_R + term] += v;
+            for (int k = 0; k < 16; ++k) v += lds[k][c];
+            const int which = col / RT, term = t0 + col % RT;
+            if (term < int_R) totals[(int64_t)which * int_R + term] += v;
+        }
+    }
+    if (do_count && g == 15) {   // exact integer sums on the last wave
+        int64_t a = 0, b = 0;
+        for (int i = c; i < nblocks; i += 64) { a += pcounts[2 * i]; b += pcounts[2 * i + 1]; }
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+        if (c == 0) { counts[0] += a; counts[1] += b; }
     }
 }
 
-__global__ void k_reduce_counts(const int64_t *__restrict__ pcounts, int nblocks, int64_t *__restrict__ counts) {
-    // one wave; exact integer sums
-    int64_t a = 0, b = 0;
-    for (int i = threadIdx.x; i < nblocks; i += 64) { a += pcounts[2 * i]; b += pcounts[2 * i + 1]; }
-    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-    if (threadIdx.x == 0) { counts[0] += a; counts[1] += b; }
-}
+struct AccLaunch {
+    bool pair;
+    int blocks_per_cu_cap;
+    const double *coef, *d_f, *d_c;
+    const uint8_t *d_mask;
+    int64_t n;
+    int t0;
+    double *partials;
+    int64_t *pcounts;
+};
 
+// launches the (KIND, RT) instantiation; *blocks_out = grid size used
 template <int KIND, int RT>
-static int launch_accum_rt(mlmc_accum *a, bool pair, int blocks, const double *coef, const double *d_f, const double *d_c,
-                           const uint8_t *d_mask, int64_t n, int t0, int R, double *partials, int64_t *pcounts) {
+static int launch_accum_rt(const BasisParams &bp, const AccLaunch &a, int *blocks_out) {
     hipStream_t st = rt().stream;
-    const BasisParams &bp = a->basis->p;
-#define MLMC_LAUNCH_ACC(P, F) hipLaunchKernelGGL((k_moments_accum<KIND, RT, P, F>), dim3(blocks), dim3(ACC_THREADS), 0, st, bp, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts)
-    if (pair && t0 == 0) MLMC_LAUNCH_ACC(true, true);
-    else if (pair) MLMC_LAUNCH_ACC(true, false);
-    else if (t0 == 0) MLMC_LAUNCH_ACC(false, true);
+    const void *fn;
+    if (a.pair && a.t0 == 0) fn = (const void *)k_moments_accum<KIND, RT, true, true>;
+    else if (a.pair) fn = (const void *)k_moments_accum<KIND, RT, true, false>;
+    else if (a.t0 == 0) fn = (const void *)k_moments_accum<KIND, RT, false, true>;
+    else fn = (const void *)k_moments_accum<KIND, RT, false, false>;
+    int per_cu = 1;
+    MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, ACC_THREADS, 0));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    int64_t want = (a.n + 2 * ACC_THREADS - 1) / (2 * ACC_THREADS);
+    int blocks = rt().n_cu * per_cu;
+    if (const char *e = getenv("MLMC_HIP_DEV_BLOCKS")) {   // development knob (grid-size experiments)
+        blocks = atoi(e);
+        if (blocks > rt().n_cu * 4) blocks = rt().n_cu * 4;
+    }
+    if (want < blocks) blocks = (int)want;
+    if (blocks < 1) blocks = 1;
+    *blocks_out = blocks;
+#define MLMC_LAUNCH_ACC(P, F) hipLaunchKernelGGL((k_moments_accum<KIND, RT, P, F>), dim3(blocks), dim3(ACC_THREADS), 0, st, bp, a.coef, a.d_f, a.d_c, a.d_mask, a.n, a.t0, a.partials, a.pcounts)
+    if (a.pair && a.t0 == 0) MLMC_LAUNCH_ACC(true, true);
+    else if (a.pair) MLMC_LAUNCH_ACC(true, false);
+    else if (a.t0 == 0) MLMC_LAUNCH_ACC(false, true);
     else MLMC_LAUNCH_ACC(false, false);
 #undef MLMC_LAUNCH_ACC
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-template <int KIND>
-static int launch_accum_kind(mlmc_accum *a, int rt_sel, bool pair, int blocks, const double *coef, const double *d_f,
-                             const double *d_c, const uint8_t *d_mask, int64_t n, int t0, int R, double *partials,
-                             int64_t *pcounts) {
-    switch (rt_sel) {
-        case 4: return launch_accum_rt<KIND, 4>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
-        case 8: return launch_accum_rt<KIND, 8>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
-        case 16: return launch_accum_rt<KIND, 16>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
-        case 32: return launch_accum_rt<KIND, 32>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
-        case 48: return launch_accum_rt<KIND, 48>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
-        default: return launch_accum_rt<KIND, 64>(a, pair, blocks, coef, d_f, d_c, d_mask, n, t0, R, partials, pcounts);
+// register-tile sizes compiled per family; a pass uses the smallest one that holds its terms
+static int pick_rt(int kind, int n_terms) {
+    if (kind == MLMC_IDENTITY) return 4;
+    if (kind == MLMC_LEGENDRE) {
+        const int opts[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+        for (int o : opts)
+            if (n_terms <= o) return o;
+        return 64;
     }
-}
-
-static int pick_rt(int n_terms) {
-    const int opts[] = {4, 8, 16, 32, 48, 64};
+    const int opts[] = {8, 16, 32, 64};
     for (int o : opts)
         if (n_terms <= o) return o;
     return 64;
 }
 
-// blocks per CU the register budget of an RT-instantiation admits (4 waves = 1 wave per SIMD per block)
-static int blocks_per_cu(int rt_sel) {
-    if (rt_sel <= 16) return 4;
-    if (rt_sel <= 32) return 2;
-    return 1;
+static int launch_accum_dispatch(const BasisParams &bp, int rt_sel, const AccLaunch &a, int *blocks_out) {
+#define MLMC_RT_CASE(KIND, N) case N: return launch_accum_rt<KIND, N>(bp, a, blocks_out)
+    switch (bp.kind) {
+        case MLMC_LEGENDRE:
+            switch (rt_sel) {
+                MLMC_RT_CASE(MLMC_LEGENDRE, 4); MLMC_RT_CASE(MLMC_LEGENDRE, 8); MLMC_RT_CASE(MLMC_LEGENDRE, 12);
+                MLMC_RT_CASE(MLMC_LEGENDRE, 16); MLMC_RT_CASE(MLMC_LEGENDRE, 20); MLMC_RT_CASE(MLMC_LEGENDRE, 24);
+                MLMC_RT_CASE(MLMC_LEGENDRE, 28); MLMC_RT_CASE(MLMC_LEGENDRE, 32); MLMC_RT_CASE(MLMC_LEGENDRE, 40);
+                MLMC_RT_CASE(MLMC_LEGENDRE, 48); MLMC_RT_CASE(MLMC_LEGENDRE, 56);
+                default: return launch_accum_rt<MLMC_LEGENDRE, 64>(bp, a, blocks_out);
+            }
+        case MLMC_MONOMIAL:
+            switch (rt_sel) {
+                MLMC_RT_CASE(MLMC_MONOMIAL, 8); MLMC_RT_CASE(MLMC_MONOMIAL, 16); MLMC_RT_CASE(MLMC_MONOMIAL, 32);
+                default: return launch_accum_rt<MLMC_MONOMIAL, 64>(bp, a, blocks_out);
+            }
+        case MLMC_FOURIER:
+            switch (rt_sel) {
+                MLMC_RT_CASE(MLMC_FOURIER, 8); MLMC_RT_CASE(MLMC_FOURIER, 16); MLMC_RT_CASE(MLMC_FOURIER, 32);
+                default: return launch_accum_rt<MLMC_FOURIER, 64>(bp, a, blocks_out);
+            }
+        case MLMC_IDENTITY: return launch_accum_rt<MLMC_IDENTITY, 4>(bp, a, blocks_out);
+        default: return fail("unknown basis kind");
+    }
+#undef MLMC_RT_CASE
 }
 
 int launch_moments_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
                          int64_t n, bool count) {
     if (n == 0) return 0;
-    hipStream_t st = rt().stream;
     const int R = a->R;
     const bool pair = d_c != nullptr;
+    const BasisParams &bp = a->basis->p;
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
     int64_t *counts = a->d_counts + (int64_t)level * 2;
     for (int t0 = 0; t0 < R; t0 += MAX_TERMS_PER_PASS) {
         const int n_terms = (R - t0 < MAX_TERMS_PER_PASS) ? R - t0 : MAX_TERMS_PER_PASS;
-        const int rt_sel = pick_rt(n_terms);
-        int64_t want = (n + 2 * ACC_THREADS - 1) / (2 * ACC_THREADS);
-        int blocks = rt().n_cu * blocks_per_cu(rt_sel);
-        if (want < blocks) blocks = (int)want;
-        if (blocks < 1) blocks = 1;
+        const int rt_sel = pick_rt(bp.kind, n_terms);
         const int width = 2 * rt_sel;
-        if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * width)) return rc;
-        if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
+        const int max_blocks = rt().n_cu * 4;
+        if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)max_blocks * width)) return rc;
+        if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)max_blocks * 2)) return rc;
         const bool do_count = count && t0 == 0;
-        int64_t *pc = do_count ? a->d_pcounts : nullptr;
+        AccLaunch al{pair, 4, a->basis->d_coef, d_f, d_c, d_mask, n, t0, a->d_partials, a->d_pcounts};
+        int blocks = 0;
         if (int rc = timing_begin(a)) return rc;
-        int rc;
-        switch (a->basis->p.kind) {
-            case MLMC_LEGENDRE: rc = launch_accum_kind<MLMC_LEGENDRE>(a, rt_sel, pair, blocks, a->basis->d_coef, d_f, d_c, d_mask, n, t0, R, a->d_partials, pc); break;
-            case MLMC_MONOMIAL: rc = launch_accum_kind<MLMC_MONOMIAL>(a, rt_sel, pair, blocks, a->basis->d_coef, d_f, d_c, d_mask, n, t0, R, a->d_partials, pc); break;
-            case MLMC_FOURIER: rc = launch_accum_kind<MLMC_FOURIER>(a, rt_sel, pair, blocks, a->basis->d_coef, d_f, d_c, d_mask, n, t0, R, a->d_partials, pc); break;
-            case MLMC_IDENTITY: rc = launch_accum_rt<MLMC_IDENTITY, 4>(a, pair, blocks, a->basis->d_coef, d_f, d_c, d_mask, n, t0, R, a->d_partials, pc); break;
-            default: return fail("unknown basis kind");
-        }
-        if (rc) return rc;
-        if (int rc2 = timing_end(a)) return rc2;
+        if (int rc = launch_accum_dispatch(bp, rt_sel, al, &blocks)) return rc;
+        if (int rc = timing_end(a)) return rc;
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, rt().stream, a->d_partials, a->d_pcounts, blocks, width, rt_sel, t0,
+                           R, do_count ? 1 : 0, totals, counts);
+        MLMC_HIP_CHECK(hipGetLastError());
         a->launches += 1;
         a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
-        const int rt_eff = (a->basis->p.kind == MLMC_IDENTITY) ? 4 : rt_sel;
-        hipLaunchKernelGGL(k_reduce_partials, dim3((2 * rt_eff + 63) / 64), dim3(1024), 0, st, a->d_partials, blocks, 2 * rt_eff,
-                           totals, rt_eff, t0, R);
-        MLMC_HIP_CHECK(hipGetLastError());
-        if (do_count) {
-            hipLaunchKernelGGL(k_reduce_counts, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, counts);
-            MLMC_HIP_CHECK(hipGetLastError());
-        }
     }
     return 0;
 }
@@ -349,9 +390,15 @@ int launch_moments_accum(mlmc_accum *a, int level, int comp, const double *d_f, 
 // ------------------------------------------------------------------------------------------
 __global__ void k_moments_finalize(const double *__restrict__ totals, const double *__restrict__ scale_c,
                                    const double *__restrict__ T, int R, int RP, int Rout, int has_T, int64_t int_width,
-                                   int n_lc, double *__restrict__ out_s, double *__restrict__ out_sp) {
+                                   int n_lc, double *__restrict__ out_s, double *__restrict__ out_sp,
+                                   const int64_t *__restrict__ counts, int n_levels, int64_t *__restrict__ out_n) {
     const int lc = blockIdx.x;   // (level, comp)
     if (lc >= n_lc) return;
+    if (lc == 0)
+        for (int l = threadIdx.x; l < n_levels; l += blockDim.x) {   // (kept, removed) pairs -> n[L], n_rm[L]
+            out_n[l] = counts[2 * l];
+            out_n[n_levels + l] = counts[2 * l + 1];
+        }
     const double *tot = totals + (int64_t)lc * int_width;
     for (int j = threadIdx.x; j < Rout; j += blockDim.x) {
         double s, sp;
@@ -380,7 +427,7 @@ int launch_moments_finalize(mlmc_accum *a) {
     const int n_lc = a->n_levels * a->n_comp;
     hipLaunchKernelGGL(k_moments_finalize, dim3(n_lc), dim3(128), 0, rt().stream, a->d_totals, a->basis->d_scale,
                        a->basis->d_matrix, a->R, a->RP, a->Rout, a->basis->out_size > 0 ? 1 : 0, a->int_width, n_lc,
-                       a->d_out_s, a->d_out_sp);
+                       a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
