@@ -1,0 +1,165 @@
+"""CPU tests of the host-side logic of the drop-in API: quantity tree bookkeeping, Memory storage, sample allocation,
+variance regression, orthogonalisation -- everything that needs no kernel."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _spec():
+    from mlmc_amd.quantity.quantity_spec import QuantitySpec
+    return [QuantitySpec(name="length", unit="m", shape=(2, 1), times=[1, 2, 3], locations=['10', '20']),
+            QuantitySpec(name="width", unit="mm", shape=(2, 1), times=[1, 2, 3], locations=['30', '40'])]
+
+
+def _storage(n=(7, 5, 3)):
+    from mlmc_amd.sample_storage import Memory
+    st = Memory()
+    st.save_global_data(result_format=_spec(), level_parameters=[[0.1], [0.01], [0.001]])
+    rng = np.random.default_rng(0)
+    M = 24
+    for l, nl in enumerate(n):
+        samples = [("L{:02d}_S{:07d}".format(l, i), (rng.normal(size=M), rng.normal(size=M) if l else np.zeros(M))) for i in range(nl)]
+        st.save_samples({l: samples}, {l: []})
+    st.save_n_ops([(0, (10.0, 7)), (1, (50.0, 5)), (2, (90.0, 3))])
+    return st
+
+
+def test_memory_storage_and_quantity_selection():
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.quantity.quantity_spec import ChunkSpec
+    st = _storage()
+    assert st.get_n_levels() == 3 and st.get_n_collected() == [7, 5, 3] and st.get_level_ids() == [0, 1, 2]
+    assert np.allclose(st.get_n_ops(), [10 / 7, 10.0, 30.0])
+    chunks = list(st.chunks())
+    assert [c.level_id for c in chunks] == [0, 1, 2] and chunks[1].chunk_slice == slice(0, 5, 1)
+    assert st.sample_pairs_level(ChunkSpec(level_id=0)).shape == (24, 7, 1)
+    assert st.sample_pairs_level(chunks[1]).shape == (24, 5, 2)
+    root = make_root_quantity(st, _spec())
+    assert root.size() == 24
+    length = root['length']
+    assert length.size() == 12
+    loc = length[2]['20']
+    assert loc.size() == 2
+    raw = st.sample_pairs_level(chunks[2])
+    # 'length' starts at 0; time 2 is the second block of 4; location '20' the second pair; flat index 4 + 2 = 6..7
+    assert np.array_equal(loc.samples(chunks[2]), raw[6:8])
+    assert np.array_equal(loc[1].samples(chunks[2]), raw[7:8])
+    width = root['width'][3]['30'][0]
+    assert np.array_equal(width.samples(chunks[1]), st.sample_pairs_level(chunks[1])[12 + 8:12 + 9])
+    # arithmetic, constants, ufuncs, masks
+    q = 2 * loc[0] + 1.0
+    assert np.allclose(q.samples(chunks[1]), 2 * raw_l1(st, 6) + 1.0)
+    assert np.allclose(np.sin(loc[0]).samples(chunks[1]), np.sin(raw_l1(st, 6)))
+    mask = loc[0] > 0.0
+    sel = loc.select(mask)
+    got = sel.samples(chunks[1])
+    r = st.sample_pairs_level(chunks[1])[6:8]
+    keep = (r[0] > 0).all(axis=-1)
+    assert got.shape == (2, int(keep.sum()), 2) and np.array_equal(got, r[:, keep, :])
+    with pytest.raises(Exception):
+        loc.select(loc[0])          # not a BoolType quantity
+    interp = length.time_interpolation(1.5)
+    assert interp.size() == 4
+    assert np.allclose(interp.samples(chunks[1]), 0.5 * (st.sample_pairs_level(chunks[1])[0:4] + st.sample_pairs_level(chunks[1])[4:8]))
+
+
+def raw_l1(st, idx):
+    return st.sample_pairs_level(list(st.chunks())[1])[idx:idx + 1]
+
+
+def test_quantity_mean_container():
+    from mlmc_amd.quantity import quantity_types as qt
+    from mlmc_amd.quantity.quantity import QuantityMean
+    qtype = qt.ArrayType((2, 3), qt.ScalarType())
+    l_means = np.arange(12, dtype=float).reshape(2, 6)
+    l_vars = np.ones((2, 6))
+    qm = QuantityMean(qtype, l_means, l_vars, n_samples=[10, 5], n_rm_samples=[1, 0])
+    assert qm.mean.shape == (2, 3) and np.array_equal(qm.mean.ravel(), l_means.sum(axis=0))
+    assert np.allclose(qm.var, 0.1 + 0.2)
+    assert qm.l_means.shape == (2, 2, 3)
+    sub = qm[1]
+    assert sub.mean.shape == (3,) and np.array_equal(sub.mean, qm.mean[1])
+
+
+def test_allocation_and_regression_host_functions():
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate, estimate_n_samples_for_target_variance, determine_level_parameters, \
+        determine_n_samples, determine_sample_vec, calc_level_params
+    with open(os.path.join(GOLDEN, "G4_alloc.json")) as f:
+        g4 = json.load(f)
+    est = Estimate(None, None, Legendre(5, (-1.0, 1.0)))
+    for key, d in g4.items():
+        if not isinstance(d, dict):
+            continue
+        raw = np.array(d["raw_vars"])
+        reg = est._all_moments_variance_regression(raw, np.array(d["steps"]))
+        assert np.allclose(reg, np.array(d["reg_vars"]), rtol=1e-12, atol=0)
+        n_est = estimate_n_samples_for_target_variance(1e-6, np.array(d["reg_vars"]), d["n_ops"], len(raw))
+        assert np.array_equal(n_est, d["n_estimated"])
+        n_est = estimate_n_samples_for_target_variance(1e-5, raw, d["n_ops"], len(raw))
+        assert np.array_equal(n_est, d["n_estimated_raw"])
+    assert determine_level_parameters(5, [0.5, 0.01]) == g4["level_params_5"]
+    assert calc_level_params([0.5, 0.01], 1) == g4["level_params_1"]
+    assert determine_n_samples(5).tolist() == g4["determine_n_samples_5"]
+    assert determine_n_samples(4, [1000, 10]).tolist() == g4["determine_n_samples_4_1000_10"]
+    assert determine_sample_vec([5, 4, 3], 2).tolist() == [5, 4]
+    # closed form of Var[log(chi2_df/df)] used in place of the reference's adaptive quadratures (estimator.py:136-169)
+    import scipy.integrate as integrate
+    import scipy.stats as st
+    est._n_created_samples = [30, 8]
+    got = est._variance_of_variance()
+    for ns, v in zip([30, 8], got):
+        df = ns - 1
+        pdf = lambda x: np.exp(x) * df * st.chi2.pdf(np.exp(x) * df, df=df)
+        m1 = integrate.quad(lambda x: x * pdf(x), -30, 10)[0]
+        m2 = integrate.quad(lambda x: x * x * pdf(x), -30, 10)[0]
+        assert abs(v - (m2 - m1 ** 2)) < 1e-7
+
+
+def test_orthogonal_moments_host():
+    from mlmc_amd import Legendre, TransformedMoments
+    from mlmc_amd.tool import simple_distribution as sd
+    g5 = np.load(os.path.join(GOLDEN, "G5_ortho.npz"))
+    for name in ("norm12", "lognorm"):
+        for R in (7, 41):
+            key = f"{name}_R{R}"
+            base = Legendre(R, tuple(g5[key + "_domain"]))
+            cov = g5[key + "_cov"]
+            for tol in (1e-4, 0.0):
+                ortho, (ev, thr, L) = sd.construct_ortogonal_moments(base, cov, tol)
+                tk = key + "_tol{:g}".format(tol)
+                assert isinstance(ortho, TransformedMoments) and ortho.size == L.shape[0]
+                assert thr == int(g5[tk + "_threshold"])
+                assert np.allclose(L, g5[tk + "_L"], rtol=1e-7, atol=1e-9)
+            ortho, (ev, thr, L) = sd.construct_ortogonal_moments(base, cov, 1e-4)
+            assert np.linalg.norm(L @ cov @ L.T - np.eye(L.shape[0])) < 1e-8      # test/test_distribution.py:180 (1e-10 there on exact cov)
+            ortho2, info2 = sd.construct_ortogonal_moments(base, cov, tol=None)    # slope-change threshold detector runs
+            assert 0 <= info2[1] < R
+
+
+def test_moments_objects_host_side():
+    from mlmc_amd import Legendre, Monomial, Fourier, TransformedMoments
+    fn = Legendre(5, (1.0, 3.0))
+    assert fn.size == 5 and fn.domain == (1.0, 3.0) and fn.ref_domain == (-1, 1)
+    assert fn._linear_scale == 1.0 and fn._linear_shift == 1.0
+    assert fn == Legendre(5, (1.0, 3.0)) and not (fn == Legendre(6, (1.0, 3.0))) and not (fn == Monomial(5, (1.0, 3.0)))
+    assert fn.change_size(9).size == 9 and isinstance(fn.change_size(9), Legendre)
+    assert np.allclose(fn.inv_transform(np.array([-1.0, 0.0, 1.0])), [1.0, 2.0, 3.0])
+    assert fn.diff_mat.shape == (5, 5) and fn.diff_mat[0, 1] == 1 and fn.diff_mat[1, 2] == 3 and fn.diff_mat[0, 3] == 1
+    lg = Monomial(3, (1.0, np.e), log=True)
+    assert np.isclose(lg._linear_shift, 0.0) and np.isclose(lg._linear_scale, 1.0)
+    assert Fourier(6).ref_domain == (0, 2 * np.pi)
+    with pytest.raises(AssertionError):
+        Legendre(0, (0, 1))
+    with pytest.raises(AssertionError):
+        Legendre(3, (1.0, 1.0))
+    tm = TransformedMoments(fn, np.eye(3, 5))
+    assert tm.size == 3 and tm.domain == fn.domain
+    tm2 = TransformedMoments(tm, np.ones((2, 3)))
+    assert tm2._base is fn and np.array_equal(tm2._base_matrix, np.ones((2, 3)) @ np.eye(3, 5))
+    with pytest.raises(AssertionError):
+        TransformedMoments(fn, np.eye(3, 4))

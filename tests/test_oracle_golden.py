@@ -212,3 +212,28 @@ def test_maxent_oracle(key):
     assert np.allclose(o.multipliers, g6[key + "_sd_multipliers"], rtol=1e-6, atol=1e-7)
     assert np.allclose(o.density(g6[key + "_xgrid"]), g6[key + "_sd_density"], rtol=1e-6, atol=1e-9)
     assert np.allclose(o.cdf(g6[key + "_xgrid"][::8]), g6[key + "_sd_cdf"], rtol=1e-6, atol=1e-8)
+
+
+def test_c_oracle_matches_numpy_oracle():
+    """oracle/oracle_c.c (compensated sums) against the NumPy oracle (pairwise sums), which is pinned bit-exact above."""
+    from oracle import oracle_c
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    steps = [0.5, 0.07, 0.01]
+    for kind in (onp.LEGENDRE, onp.MONOMIAL):
+        for R in (1, 5, 32):
+            b = onp.Basis(kind, R, dom)
+            for l in (0, 2):
+                f, c = onp.synth_level_samples(l, 20000, steps)
+                f[::17] = np.nan
+                nk, nr, s, sp = oracle_c.moments_level(b, f, c)
+                x = f[None, :, None] if c is None else np.stack([f, c], axis=-1)[None]
+                chunks = [[x]] if l == 0 else [[x[:, :1, :1]], [x]]
+                r = onp.estimate_mean(chunks, lambda x: onp.moments_rows(b, x))
+                assert nk == r.n_samples[-1] and nr == r.n_rm_samples[-1]
+                assert np.allclose(s, r.sums[-1], rtol=1e-12, atol=1e-9) and np.allclose(sp, r.sums_sq[-1], rtol=1e-12, atol=1e-9)
+    b = onp.Basis(onp.LEGENDRE, 8, dom)
+    f, c = onp.synth_level_samples(1, 3000, steps)
+    nk, nr, s, sp = oracle_c.cov_level(b, f, c)
+    x = np.stack([f, c], axis=-1)[None]
+    r = onp.estimate_mean([[x[:, :1, :1]], [x]], lambda x: onp.covariance_rows(b, x))
+    assert nk == r.n_samples[1] and np.allclose(s, r.sums[1], rtol=1e-12, atol=1e-10) and np.allclose(sp, r.sums_sq[1], rtol=1e-12, atol=1e-10)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condense the raw rocprofv3 output of tools/collect_profiles.sh (gpurun_out/<round>/) into profiles/<round>_*."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join("gpurun_out", rnd)
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(src, pattern))
+    return f[0] if f else None
+
+
+for cfg in ("c2", "c3"):
+    f = one(f"trace_{cfg}/*/*_kernel_stats.csv")
+    if f:
+        rows = list(csv.DictReader(open(f)))
+        with open(os.path.join(dst, f"{rnd}_kernel_stats_config{cfg[1]}.csv"), "w", newline="") as out:
+            w = csv.writer(out)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    summary = {}
+    for kind in ("fetch", "write", "sq"):
+        f = one(f"pmc_{kind}_{cfg}/*/*_counter_collection.csv")
+        if not f:
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        meta = {}
+        for r in csv.DictReader(open(f)):
+            if "mlmc::" not in r["Kernel_Name"]:
+                continue
+            k = r["Kernel_Name"].split("(")[0][:80]
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = dict(grid=r["Grid_Size"], wg=r["Workgroup_Size"], vgpr=r["VGPR_Count"], agpr=r["Accum_VGPR_Count"],
+                           sgpr=r["SGPR_Count"], lds=r["LDS_Block_Size"])
+        for k, v in agg.items():
+            e = summary.setdefault(k, dict(meta[k]))
+            for c, x in v.items():
+                e[c + "_avg_per_dispatch"] = sum(x) / len(x)
+                e["dispatches_" + kind] = len(x)
+    if summary:
+        with open(os.path.join(dst, f"{rnd}_pmc_config{cfg[1]}.json"), "w") as out:
+            json.dump(summary, out, indent=1, sort_keys=True)
+    for name in (f"bench_{cfg}.json",):
+        p = os.path.join(src, name)
+        if os.path.exists(p) and os.path.getsize(p):
+            with open(p) as fi, open(os.path.join(dst, f"{rnd}_{name}"), "w") as fo:
+                fo.write(fi.read())
+print("profiles written:", sorted(os.listdir(dst)))
