@@ -84,7 +84,9 @@ int mlmc_accum_reset(mlmc_accum *a);
 /* One chunk of level `level`: fine[m * n + k], coarse[m * n + k] (coarse == NULL at level 0:
  * SampleStorage.sample_pairs_level returns [M, n, 1] there, sample_storage.py:261-285).
  * Replaces eval_moments/eval_cov + mask_nan_samples + the two np.sum of quantity_estimate.py:43-65.
- * Asynchronous on the library's stream; host buffers are staged before the call returns. */
+ * Asynchronous on the library's stream.  Host buffers are staged before the call returns; DEVICE buffers must stay
+ * valid until the next mlmc_accum_finalize / mlmc_accum_reset: chunks of different levels are gathered and processed
+ * by ONE kernel launch (one grid for a whole multi-level estimate). */
 int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const double *coarse, int64_t n, int mem_kind);
 /* Writes per level l: n[l] (kept samples), n_rm[l] (NaN-masked samples), s[l * K + k] = sum of
  * level differences, sp[l * K + k] = sum of squared differences (quantity_estimate.py:46-47,64-65).

@@ -10,7 +10,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmlmc_hip.so")
+LIB_PATH = os.environ.get("MLMC_HIP_LIB", os.path.join(_HERE, "libmlmc_hip.so"))   # env override: development builds
 
 LEGENDRE, MONOMIAL, FOURIER, IDENTITY = 0, 1, 2, 3
 MODE_MOMENTS, MODE_COV = 0, 1

@@ -247,6 +247,7 @@ int mlmc_accum_reset(mlmc_accum *a) {
     if (need_runtime()) return 1;
     if (!a) return fail("mlmc_accum_reset: null argument");
     hipStream_t st = rt().stream;
+    a->pending.clear();
     MLMC_HIP_CHECK(hipMemsetAsync(a->d_state, 0, a->state_bytes, st));
     a->ev_used = 0;
     a->ms_total = 0;
@@ -315,7 +316,9 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
         const bool count = count_in_kernel && m == 0;
         int rc;
         if (a->mode == MLMC_MODE_MOMENTS) {
-            rc = launch_moments_accum(a, level, m, f_m, c_m, d_mask, n, count);
+            // chunks that stay valid until finalize (device memory, no staging / mask scratch) are gathered into one launch
+            const bool defer = mem_kind == MLMC_DEVICE && a->n_comp == 1;
+            rc = launch_moments_accum(a, level, m, f_m, c_m, d_mask, n, count, defer);
             if (!rc && a->basis->out_size > 0) rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, false, true);
         } else {
             rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, count, false);
@@ -329,6 +332,8 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
     if (need_runtime()) return 1;
     if (!a || !n || !n_rm || !s || !sp) return fail("mlmc_accum_finalize: null argument");
     hipStream_t st = rt().stream;
+    if (a->mode == MLMC_MODE_MOMENTS)
+        if (int rcf = flush_moments(a)) return rcf;
     int rc = (a->mode == MLMC_MODE_MOMENTS) ? launch_moments_finalize(a) : launch_cov_finalize(a);
     if (rc) return rc;
     const int L = a->n_levels;

@@ -53,6 +53,14 @@ struct mlmc_basis {
     double *d_matrix = nullptr;       // device: matrix [out_size][size]
 };
 
+struct PendingSeg {   // a pushed chunk waiting for the next accumulation launch
+    const double *fine, *coarse;
+    const uint8_t *mask;
+    int64_t n;
+    int level, comp;
+    bool count;
+};
+
 struct mlmc_accum {
     const mlmc_basis *basis = nullptr;
     int n_levels = 0, mode = 0, n_comp = 1;
@@ -82,6 +90,7 @@ struct mlmc_accum {
     double ms_total = 0;
     int64_t launches = 0, alg_bytes = 0;
     int RP = 0;  // COV: R padded to 16
+    std::vector<PendingSeg> pending;   // MOMENTS: chunks gathered into one launch (flushed by finalize / conflicts)
 };
 
 namespace mlmc {
@@ -89,7 +98,8 @@ namespace mlmc {
 int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, double *d_out);
 int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64_t n, uint8_t *d_mask, int64_t *d_counts_level);
 int launch_moments_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
-                         int64_t n, bool count);
+                         int64_t n, bool count, bool defer);
+int flush_moments(mlmc_accum *a);
 int launch_moments_finalize(mlmc_accum *a);
 // cov.hip
 int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,

@@ -11,6 +11,7 @@
 // wave shuffles + LDS for the block partial, and a fixed-order second kernel for the grid reduction
 // (bitwise reproducible run to run).
 #include <cstdlib>
+#include <cstring>
 
 #include "device_basis.hpp"
 
@@ -121,28 +122,40 @@ int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64
 // The accumulation kernel.
 //   RT    : accumulators per lane for sum(d) and sum(d^2): terms [t0, t0 + RT) of this pass (terms >= R, if any,
 //           are computed and discarded, so the loop body is one branch-free basic block)
-//   PAIR  : level >= 1 (fine and coarse) / level 0 (fine only)
 //   FIRST : t0 == 0 (every term index is a compile-time constant)
-// Each lane walks the samples with a grid stride, two samples per trip (four independent recurrences when
-// PAIR) so that the fp64 pipe always has independent work; the next trip's loads are issued before the
-// current trip's arithmetic.  Per pair and term: mul + fma (fine), mul + fma (coarse), sub, add, fma = 7 fp64
-// instructions (the reference's NumPy path does 14 R flops per pair in ~10 R array passes).
+// One launch covers up to MAX_SEG segments (= pushed chunks of different levels): every block belongs to one
+// segment and the segments get blocks in proportion to their work, so a whole multi-level estimate is ONE grid
+// with one ramp-up and one tail.  Within a segment each lane walks the samples with a stride, two samples per trip
+// (four independent recurrences for a fine/coarse pair) so that the fp64 pipe always has independent work; the next
+// trip's loads are issued before the current trip's arithmetic.  Per pair and term: mul + fma (fine), mul + fma
+// (coarse), sub, add, fma = 7 fp64 instructions (level 0: 4).
 // ------------------------------------------------------------------------------------------
-template <int KIND, int RT, bool PAIR, bool FIRST>
-__global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, const double *__restrict__ coef,
-                                                              const double *__restrict__ fine,
-                                                              const double *__restrict__ coarse,
-                                                              const uint8_t *__restrict__ mask, int64_t n, int t0_arg,
-                                                              double *__restrict__ partials,
-                                                              int64_t *__restrict__ pcounts) {
-    const int t0 = FIRST ? 0 : t0_arg;
-    double s[RT], sp[RT];
-#pragma unroll
-    for (int i = 0; i < RT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
-    int n_keep = 0, n_rm = 0;
+constexpr int MAX_SEG = 8;
+struct Seg {
+    const double *fine, *coarse;   // coarse == nullptr: level 0
+    const uint8_t *mask;           // optional keep flags (quantities with M > 1 components)
+    int64_t n;
+    int block0, nblocks;           // blocks [block0, block0 + nblocks) of the grid work on this segment
+};
+struct SegTable {
+    int nseg, pad;
+    Seg seg[MAX_SEG];
+};
+struct ReduceTarget {
+    double *totals;                // [2][int_R] of this segment's (level, component)
+    int64_t *counts;               // (kept, removed) of the level; nullptr: do not count
+};
+struct ReduceTable {
+    ReduceTarget t[MAX_SEG];
+};
 
-    const int64_t T = (int64_t)gridDim.x * ACC_THREADS;
-    const int64_t gtid = (int64_t)blockIdx.x * ACC_THREADS + threadIdx.x;
+template <int KIND, int RT, bool PAIR, bool FIRST>
+__device__ __forceinline__ void accum_samples(const BasisParams &bp, const double *__restrict__ coef,
+                                              const double *__restrict__ fine, const double *__restrict__ coarse,
+                                              const uint8_t *__restrict__ mask, int64_t n, int t0, int bid, int nb,
+                                              double (&s)[RT], double (&sp)[RT], int &n_keep, int &n_rm) {
+    const int64_t T = (int64_t)nb * ACC_THREADS;
+    const int64_t gtid = (int64_t)bid * ACC_THREADS + threadIdx.x;
 
     int64_t i0 = gtid, i1 = gtid + T;
     double f0 = 0, f1 = 0, c0 = 0, c1 = 0;
@@ -194,6 +207,28 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, c
         i0 = j0;
         i1 = j1;
     }
+}
+
+template <int KIND, int RT, bool FIRST>
+__global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, const double *__restrict__ coef, SegTable tab,
+                                                              int t0_arg, double *__restrict__ partials,
+                                                              int64_t *__restrict__ pcounts) {
+    const int t0 = FIRST ? 0 : t0_arg;
+    // segment of this block: static indices only, so the table stays in scalar registers
+    Seg sg = tab.seg[0];
+#pragma unroll
+    for (int k = 1; k < MAX_SEG; ++k)
+        if (k < tab.nseg && (int)blockIdx.x >= tab.seg[k].block0) sg = tab.seg[k];
+    const int bid = (int)blockIdx.x - sg.block0;
+
+    double s[RT], sp[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
+    int n_keep = 0, n_rm = 0;
+    if (sg.coarse)
+        accum_samples<KIND, RT, true, FIRST>(bp, coef, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+    else
+        accum_samples<KIND, RT, false, FIRST>(bp, coef, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
 
     // ---- block partial: the four waves add their lanes' accumulators into one LDS image [value][lane] in a
     // fixed order, then one thread per value sums the 64 lanes (row stride 65: conflict-free both ways) ----
@@ -228,22 +263,27 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, c
     }
 }
 
-// Grid reduction of one accumulation launch, one 1024-thread block, fixed order (bitwise reproducible):
-//   totals[which][t0 + i] += sum_b partials[b][which * RT + i],   counts += sum_b pcounts[b]
+// Grid reduction of one accumulation launch: block k (1024 threads) sums the partial rows of segment k in a fixed
+// order (bitwise reproducible): totals[which][t0 + i] += sum_b partials[b][which * RT + i], counts += sum_b pcounts[b].
 // 16 row groups x 64 columns, every thread keeps its <= 32 row loads in flight.  (Measured alternative: letting the
 // last-arriving block of the accumulation kernel do this behind an agent-scope release / acquire costs ~13 us of
 // kernel tail per launch -- every block's L2 write-back -- against ~4 us for this launch.)
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials,
-                                                         const int64_t *__restrict__ pcounts, int nblocks, int width, int RT,
-                                                         int t0, int int_R, int do_count, double *__restrict__ totals,
-                                                         int64_t *__restrict__ counts) {
+                                                         const int64_t *__restrict__ pcounts, SegTable tab, ReduceTable rtab,
+                                                         int width, int RT, int t0, int int_R) {
     __shared__ double lds[16][64];
+    Seg sg = tab.seg[0];
+    ReduceTarget tg = rtab.t[0];
+#pragma unroll
+    for (int k = 1; k < MAX_SEG; ++k)
+        if ((int)blockIdx.x == k) { sg = tab.seg[k]; tg = rtab.t[k]; }
+    const int row0 = sg.block0, nblocks = sg.nblocks;
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     for (int c0 = 0; c0 < width; c0 += 64) {
         const int col = c0 + c;
         double acc = 0.0;
         if (col < width) {
-            const double *__restrict__ pc = partials + col;
+            const double *__restrict__ pc = partials + (int64_t)row0 * width + col;
 #pragma unroll 8
             for (int b = g; b < nblocks; b += 16) acc += pc[(int64_t)b * width];
         }
@@ -255,57 +295,32 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restri
 #pragma unroll
             for (int k = 0; k < 16; ++k) v += lds[k][c];
             const int which = col / RT, term = t0 + col % RT;
-            if (term < int_R) totals[(int64_t)which * int_R + term] += v;
+            if (term < int_R) tg.totals[(int64_t)which * int_R + term] += v;
         }
     }
-    if (do_count && g == 15) {   // exact integer sums on the last wave
+    if (tg.counts && g == 15) {   // exact integer sums on the last wave
         int64_t a = 0, b = 0;
-        for (int i = c; i < nblocks; i += 64) { a += pcounts[2 * i]; b += pcounts[2 * i + 1]; }
+        for (int i = c; i < nblocks; i += 64) { a += pcounts[2 * (int64_t)(row0 + i)]; b += pcounts[2 * (int64_t)(row0 + i) + 1]; }
         for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-        if (c == 0) { counts[0] += a; counts[1] += b; }
+        if (c == 0) { tg.counts[0] += a; tg.counts[1] += b; }
     }
 }
 
-struct AccLaunch {
-    bool pair;
-    int blocks_per_cu_cap;
-    const double *coef, *d_f, *d_c;
-    const uint8_t *d_mask;
-    int64_t n;
-    int t0;
-    double *partials;
-    int64_t *pcounts;
-};
-
-// launches the (KIND, RT) instantiation; *blocks_out = grid size used
 template <int KIND, int RT>
-static int launch_accum_rt(const BasisParams &bp, const AccLaunch &a, int *blocks_out) {
+static int launch_accum_rt(const BasisParams &bp, const double *coef, const SegTable &tab, int total_blocks, int t0,
+                           double *partials, int64_t *pcounts) {
     hipStream_t st = rt().stream;
-    const void *fn;
-    if (a.pair && a.t0 == 0) fn = (const void *)k_moments_accum<KIND, RT, true, true>;
-    else if (a.pair) fn = (const void *)k_moments_accum<KIND, RT, true, false>;
-    else if (a.t0 == 0) fn = (const void *)k_moments_accum<KIND, RT, false, true>;
-    else fn = (const void *)k_moments_accum<KIND, RT, false, false>;
-    int per_cu = 1;
-    MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, ACC_THREADS, 0));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;
-    int64_t want = (a.n + 2 * ACC_THREADS - 1) / (2 * ACC_THREADS);
-    int blocks = rt().n_cu * per_cu;
-    if (const char *e = getenv("MLMC_HIP_DEV_BLOCKS")) {   // development knob (grid-size experiments)
-        blocks = atoi(e);
-        if (blocks > rt().n_cu * 4) blocks = rt().n_cu * 4;
-    }
-    if (want < blocks) blocks = (int)want;
-    if (blocks < 1) blocks = 1;
-    *blocks_out = blocks;
-#define MLMC_LAUNCH_ACC(P, F) hipLaunchKernelGGL((k_moments_accum<KIND, RT, P, F>), dim3(blocks), dim3(ACC_THREADS), 0, st, bp, a.coef, a.d_f, a.d_c, a.d_mask, a.n, a.t0, a.partials, a.pcounts)
-    if (a.pair && a.t0 == 0) MLMC_LAUNCH_ACC(true, true);
-    else if (a.pair) MLMC_LAUNCH_ACC(true, false);
-    else if (a.t0 == 0) MLMC_LAUNCH_ACC(false, true);
-    else MLMC_LAUNCH_ACC(false, false);
-#undef MLMC_LAUNCH_ACC
+    if (t0 == 0)
+        hipLaunchKernelGGL((k_moments_accum<KIND, RT, true>), dim3(total_blocks), dim3(ACC_THREADS), 0, st, bp, coef, tab, t0, partials, pcounts);
+    else
+        hipLaunchKernelGGL((k_moments_accum<KIND, RT, false>), dim3(total_blocks), dim3(ACC_THREADS), 0, st, bp, coef, tab, t0, partials, pcounts);
     MLMC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int KIND, int RT>
+static int occupancy_rt(int *per_cu) {
+    MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, (const void *)k_moments_accum<KIND, RT, true>, ACC_THREADS, 0));
     return 0;
 }
 
@@ -324,8 +339,11 @@ static int pick_rt(int kind, int n_terms) {
     return 64;
 }
 
-static int launch_accum_dispatch(const BasisParams &bp, int rt_sel, const AccLaunch &a, int *blocks_out) {
-#define MLMC_RT_CASE(KIND, N) case N: return launch_accum_rt<KIND, N>(bp, a, blocks_out)
+// op 0: *out = resident blocks per CU of the instantiation; op 1: launch
+static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const double *coef, const SegTable *tab, int total_blocks,
+                          int t0, double *partials, int64_t *pcounts, int *out) {
+#define MLMC_RT_CASE(KIND, N) \
+    case N: return op == 0 ? occupancy_rt<KIND, N>(out) : launch_accum_rt<KIND, N>(bp, coef, *tab, total_blocks, t0, partials, pcounts)
     switch (bp.kind) {
         case MLMC_LEGENDRE:
             switch (rt_sel) {
@@ -333,51 +351,105 @@ static int launch_accum_dispatch(const BasisParams &bp, int rt_sel, const AccLau
                 MLMC_RT_CASE(MLMC_LEGENDRE, 16); MLMC_RT_CASE(MLMC_LEGENDRE, 20); MLMC_RT_CASE(MLMC_LEGENDRE, 24);
                 MLMC_RT_CASE(MLMC_LEGENDRE, 28); MLMC_RT_CASE(MLMC_LEGENDRE, 32); MLMC_RT_CASE(MLMC_LEGENDRE, 40);
                 MLMC_RT_CASE(MLMC_LEGENDRE, 48); MLMC_RT_CASE(MLMC_LEGENDRE, 56);
-                default: return launch_accum_rt<MLMC_LEGENDRE, 64>(bp, a, blocks_out);
+                default: return op == 0 ? occupancy_rt<MLMC_LEGENDRE, 64>(out)
+                                        : launch_accum_rt<MLMC_LEGENDRE, 64>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
             }
         case MLMC_MONOMIAL:
             switch (rt_sel) {
                 MLMC_RT_CASE(MLMC_MONOMIAL, 8); MLMC_RT_CASE(MLMC_MONOMIAL, 16); MLMC_RT_CASE(MLMC_MONOMIAL, 32);
-                default: return launch_accum_rt<MLMC_MONOMIAL, 64>(bp, a, blocks_out);
+                default: return op == 0 ? occupancy_rt<MLMC_MONOMIAL, 64>(out)
+                                        : launch_accum_rt<MLMC_MONOMIAL, 64>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
             }
         case MLMC_FOURIER:
             switch (rt_sel) {
                 MLMC_RT_CASE(MLMC_FOURIER, 8); MLMC_RT_CASE(MLMC_FOURIER, 16); MLMC_RT_CASE(MLMC_FOURIER, 32);
-                default: return launch_accum_rt<MLMC_FOURIER, 64>(bp, a, blocks_out);
+                default: return op == 0 ? occupancy_rt<MLMC_FOURIER, 64>(out)
+                                        : launch_accum_rt<MLMC_FOURIER, 64>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
             }
-        case MLMC_IDENTITY: return launch_accum_rt<MLMC_IDENTITY, 4>(bp, a, blocks_out);
+        case MLMC_IDENTITY:
+            return op == 0 ? occupancy_rt<MLMC_IDENTITY, 4>(out)
+                           : launch_accum_rt<MLMC_IDENTITY, 4>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
         default: return fail("unknown basis kind");
     }
 #undef MLMC_RT_CASE
 }
 
-int launch_moments_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
-                         int64_t n, bool count) {
-    if (n == 0) return 0;
+// Launch the pending segments of `a` (all passes over the terms), then the grid reduction.
+int flush_moments(mlmc_accum *a) {
+    const int nseg = (int)a->pending.size();
+    if (nseg == 0) return 0;
+    hipStream_t st = rt().stream;
     const int R = a->R;
-    const bool pair = d_c != nullptr;
     const BasisParams &bp = a->basis->p;
-    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
-    int64_t *counts = a->d_counts + (int64_t)level * 2;
     for (int t0 = 0; t0 < R; t0 += MAX_TERMS_PER_PASS) {
         const int n_terms = (R - t0 < MAX_TERMS_PER_PASS) ? R - t0 : MAX_TERMS_PER_PASS;
         const int rt_sel = pick_rt(bp.kind, n_terms);
         const int width = 2 * rt_sel;
-        const int max_blocks = rt().n_cu * 4;
-        if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)max_blocks * width)) return rc;
-        if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)max_blocks * 2)) return rc;
-        const bool do_count = count && t0 == 0;
-        AccLaunch al{pair, 4, a->basis->d_coef, d_f, d_c, d_mask, n, t0, a->d_partials, a->d_pcounts};
-        int blocks = 0;
+        int per_cu = 1;
+        if (int rc = accum_dispatch(0, bp, rt_sel, nullptr, nullptr, 0, 0, nullptr, nullptr, &per_cu)) return rc;
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 4) per_cu = 4;
+        const int resident = rt().n_cu * per_cu;
+        // blocks per segment in proportion to its work: 7 fp64 instructions per pair and term, 4 at level 0 plus the
+        // per-sample overhead (measured time ratio pair : level-0 = 1.5 at R = 32)
+        const double W_PAIR = 7.0;
+        double W_SINGLE = 4.3;
+        if (const char *e = getenv("MLMC_HIP_DEV_WSINGLE")) W_SINGLE = atof(e);   // development knob
+        double wsum = 0.0;
+        for (const PendingSeg &p : a->pending) wsum += (double)p.n * (p.coarse ? W_PAIR : W_SINGLE);
+        SegTable tab;
+        ReduceTable rtab;
+        std::memset(&tab, 0, sizeof(tab));
+        std::memset(&rtab, 0, sizeof(rtab));
+        tab.nseg = nseg;
+        int total = 0;
+        int64_t bytes = 0;
+        for (int k = 0; k < nseg; ++k) {
+            const PendingSeg &p = a->pending[k];
+            // floor: the whole grid must be resident at once (one block over the limit would run as a second round)
+            int nb = (int)((double)resident * ((double)p.n * (p.coarse ? W_PAIR : W_SINGLE)) / wsum);
+            const int64_t want = (p.n + 2 * ACC_THREADS - 1) / (2 * ACC_THREADS);
+            if (nb > want) nb = (int)want;
+            if (nb < 1) nb = 1;
+            tab.seg[k].fine = p.fine;
+            tab.seg[k].coarse = p.coarse;
+            tab.seg[k].mask = p.mask;
+            tab.seg[k].n = p.n;
+            tab.seg[k].block0 = total;
+            tab.seg[k].nblocks = nb;
+            total += nb;
+            rtab.t[k].totals = a->d_totals + ((int64_t)p.level * a->n_comp + p.comp) * a->int_width;
+            rtab.t[k].counts = (p.count && t0 == 0) ? a->d_counts + (int64_t)p.level * 2 : nullptr;
+            bytes += p.n * (p.coarse ? 16 : 8);
+        }
+        if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)total * width)) return rc;
+        if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)total * 2)) return rc;
         if (int rc = timing_begin(a)) return rc;
-        if (int rc = launch_accum_dispatch(bp, rt_sel, al, &blocks)) return rc;
+        if (int rc = accum_dispatch(1, bp, rt_sel, a->basis->d_coef, &tab, total, t0, a->d_partials, a->d_pcounts, nullptr)) return rc;
         if (int rc = timing_end(a)) return rc;
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, rt().stream, a->d_partials, a->d_pcounts, blocks, width, rt_sel, t0,
-                           R, do_count ? 1 : 0, totals, counts);
-        MLMC_HIP_CHECK(hipGetLastError());
         a->launches += 1;
-        a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
+        a->alg_bytes += bytes;
+        hipLaunchKernelGGL(k_reduce_partials, dim3(nseg), dim3(1024), 0, st, a->d_partials, a->d_pcounts, tab, rtab, width, rt_sel, t0, R);
+        MLMC_HIP_CHECK(hipGetLastError());
     }
+    a->pending.clear();
+    return 0;
+}
+
+// Queue one chunk (device pointers).  Chunks of different levels are gathered into one launch; a second chunk of a
+// level that is already queued (or a full table) flushes first.  `defer` false: launch immediately.
+int launch_moments_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
+                         int64_t n, bool count, bool defer) {
+    if (n == 0) return 0;
+    for (const PendingSeg &p : a->pending)
+        if (p.level == level && p.comp == comp) {
+            if (int rc = flush_moments(a)) return rc;
+            break;
+        }
+    if ((int)a->pending.size() >= MAX_SEG)
+        if (int rc = flush_moments(a)) return rc;
+    a->pending.push_back(PendingSeg{d_f, d_c, d_mask, n, level, comp, count});
+    if (!defer) return flush_moments(a);
     return 0;
 }
 
