@@ -81,17 +81,18 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum(BasisParams bp, const doub
             if (nidx < n) { xv = src[nidx]; if (mask) mv = mask[nidx]; }
             TermGen<KIND> g;
             g.init(keep ? t : 0.0, keep ? 1.0 : 0.0);
-#pragma unroll 8
-            for (int i = 0; i < NT; ++i) {
-                double q = (i < R) ? g.next(i, coef) : 0.0;
-                dst[i * COV_LDS_STRIDE + samp] = q;
-            }
+            // all NT terms, fully unrolled (compile-time indices, no branches); rows >= R of the Gram matrices are
+            // never read back
+#pragma unroll
+            for (int i = 0; i < NT; ++i) dst[i * COV_LDS_STRIDE + samp] = g.next(i, coef);
         }
         __syncthreads();
         // ---------------- phase 2: MFMA over the batch ----------------
         const int arow = 16 * I + (lane & 15);
-#pragma unroll 2
-        for (int ks = kslice; ks < COV_BATCH / 4; ks += NSL) {
+        // fixed trip count -> fully unrolled: the compiler hoists the next steps' LDS reads above the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < COV_BATCH / 4 / NSL; ++kk) {
+            const int ks = kslice + kk * NSL;
             const int col = 4 * ks + (lane >> 4);
             double fa = lds_f[arow * COV_LDS_STRIDE + col];
             double da = fa, sa = fa;
