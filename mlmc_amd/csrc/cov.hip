@@ -24,8 +24,10 @@ constexpr int COV_BATCH = 64;
 constexpr int COV_LDS_STRIDE = 66;   // doubles per term row: == 2 (mod 32) -> ds_read_b64 fragments hit 32 distinct bank pairs
 
 // MODE 0: G0, G1, G2 (covariance mean + variance);  MODE 1: G = D^T D only (variance of transformed moments)
-template <int KIND, int T, bool PAIR, int MODE>
-__global__ __launch_bounds__(256, 2) void k_cov_accum(BasisParams bp, const double *__restrict__ coef,
+// BI, BJ (T = 4 only): the 64 x 64 output block (rows = terms [64 BI, 64 BI + 64), columns = terms [64 BJ, ...)) of
+// a covariance with more than 64 moments; off-diagonal blocks keep two term windows in LDS (one workgroup per CU).
+template <int KIND, int T, bool PAIR, int MODE, int BI = 0, int BJ = 0>
+__global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisParams bp, const double *__restrict__ coef,
                                                       const double *__restrict__ fine,
                                                       const double *__restrict__ coarse,
                                                       const uint8_t *__restrict__ mask, int64_t n, int R,
@@ -33,8 +35,14 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum(BasisParams bp, const doub
     constexpr int NT = 16 * T;                 // terms held in LDS
     constexpr int NSL = 4 / T;                 // k-slices (waves sharing a row tile split the samples)
     constexpr int NG = (MODE == 0) ? (PAIR ? 3 : 2) : 1;
+    constexpr bool WIDE = BI != BJ;            // two different term windows
+    constexpr int TA = 64 * BI, TB = 64 * BJ;  // first term of the row / column window
+    constexpr int N_EVAL = (BI > BJ ? TA : TB) + NT;   // terms the recurrence has to run through
+    static_assert(T == 4 || (BI == 0 && BJ == 0), "term windows need T = 4");
     __shared__ double lds_f[NT * COV_LDS_STRIDE];
     __shared__ double lds_c[PAIR ? NT * COV_LDS_STRIDE : 1];
+    __shared__ double lds_fb[WIDE ? NT * COV_LDS_STRIDE : 1];              // column window (off-diagonal blocks)
+    __shared__ double lds_cb[(WIDE && PAIR) ? NT * COV_LDS_STRIDE : 1];
     __shared__ int ldc[2][2];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -53,6 +61,7 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum(BasisParams bp, const doub
     const bool is_coarse = PAIR && (lane >> 5);
     const double *__restrict__ src = is_coarse ? coarse : fine;
     double *__restrict__ dst = is_coarse ? lds_c : lds_f;
+    double *__restrict__ dst_b = WIDE ? (is_coarse ? lds_cb : lds_fb) : dst;
     int n_keep = 0, n_rm = 0;
 
     const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
@@ -84,7 +93,11 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum(BasisParams bp, const doub
             // all NT terms, fully unrolled (compile-time indices, no branches); rows >= R of the Gram matrices are
             // never read back
 #pragma unroll
-            for (int i = 0; i < NT; ++i) dst[i * COV_LDS_STRIDE + samp] = g.next(i, coef);
+            for (int i = 0; i < N_EVAL; ++i) {
+                const double q = g.next(i, coef);
+                if (i >= TA && i < TA + NT) dst[(i - TA) * COV_LDS_STRIDE + samp] = q;
+                if (WIDE && i >= TB && i < TB + NT) dst_b[(i - TB) * COV_LDS_STRIDE + samp] = q;
+            }
         }
         __syncthreads();
         // ---------------- phase 2: MFMA over the batch ----------------
@@ -105,10 +118,10 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum(BasisParams bp, const doub
 #pragma unroll
             for (int J = 0; J < T; ++J) {
                 const int brow = 16 * J + (lane & 15);
-                double fb = lds_f[brow * COV_LDS_STRIDE + col];
+                double fb = (WIDE ? lds_fb : lds_f)[brow * COV_LDS_STRIDE + col];
                 double db = fb, sb = fb;
                 if (PAIR) {
-                    double cb = lds_c[brow * COV_LDS_STRIDE + col];
+                    double cb = (WIDE ? lds_cb : lds_c)[brow * COV_LDS_STRIDE + col];
                     db = fb - cb;
                     sb = fb + cb;
                 }
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum(BasisParams bp, const doub
 
 // totals[g][row][col] (leading dimension RP) += sum over partial rows, fixed order.
 __global__ __launch_bounds__(1024) void k_reduce_cov(const double *__restrict__ partials, int nrows, int NT, int NG, int RP,
-                                                    double *__restrict__ totals) {
+                                                    int roff, int coff, double *__restrict__ totals) {
     __shared__ double lds[16][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int width = NG * NT * NT;
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(1024) void k_reduce_cov(const double *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += lds[k][c];
         const int gi = col / (NT * NT), rem = col % (NT * NT);
-        const int row = rem / NT, cc = rem % NT;
+        const int row = roff + rem / NT, cc = coff + rem % NT;
         if (row < RP && cc < RP) totals[(int64_t)gi * RP * RP + (int64_t)row * RP + cc] += v;
     }
 }
@@ -193,74 +206,83 @@ __global__ void k_reduce_counts2(const int64_t *__restrict__ pcounts, int nblock
     if (threadIdx.x == 0) { counts[0] += a; counts[1] += b; }
 }
 
-template <int KIND, int T, int MODE>
+template <int KIND, int T, int MODE, int BI, int BJ>
 static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, const double *coef, const double *d_f, const double *d_c,
                         const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
     hipStream_t st = rt().stream;
     if (pair)
-        hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+        hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE, BI, BJ>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
     else
-        hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+        hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE, BI, BJ>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 template <int KIND, int MODE>
-static int launch_cov_kind(const BasisParams &bp, int T, bool pair, int blocks, const double *coef, const double *d_f,
+static int launch_cov_kind(const BasisParams &bp, int T, int bi, int bj, bool pair, int blocks, const double *coef, const double *d_f,
                            const double *d_c, const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
-    switch (T) {
-        case 1: return launch_cov_t<KIND, 1, MODE>(bp, pair, blocks, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
-        case 2: return launch_cov_t<KIND, 2, MODE>(bp, pair, blocks, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
-        default: return launch_cov_t<KIND, 4, MODE>(bp, pair, blocks, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
-    }
+#define MLMC_COV_ARGS bp, pair, blocks, coef, d_f, d_c, d_mask, n, R, partials, pcounts
+    if (T == 1) return launch_cov_t<KIND, 1, MODE, 0, 0>(MLMC_COV_ARGS);
+    if (T == 2) return launch_cov_t<KIND, 2, MODE, 0, 0>(MLMC_COV_ARGS);
+    if (bi == 0 && bj == 0) return launch_cov_t<KIND, 4, MODE, 0, 0>(MLMC_COV_ARGS);
+    if (bi == 0 && bj == 1) return launch_cov_t<KIND, 4, MODE, 0, 1>(MLMC_COV_ARGS);
+    if (bi == 1 && bj == 0) return launch_cov_t<KIND, 4, MODE, 1, 0>(MLMC_COV_ARGS);
+    if (bi == 1 && bj == 1) return launch_cov_t<KIND, 4, MODE, 1, 1>(MLMC_COV_ARGS);
+#undef MLMC_COV_ARGS
+    return fail("covariance: at most 128 moments");
 }
 
 int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
                      int64_t n, bool count, bool diff_gram_only) {
     if (n == 0) return 0;
     const int R = a->R;
-    if (R > 64) return fail("covariance accumulation supports at most 64 moments per pass on the device path (R > 64: not yet)");
+    if (R > 128) return fail("covariance accumulation supports at most 128 moments on the device path");
     hipStream_t st = rt().stream;
     const int T = (R <= 16) ? 1 : (R <= 32 ? 2 : 4);
     const int NT = 16 * T, NSL = 4 / T;
     const int NG = diff_gram_only ? 1 : 3;
+    const int NB = (R + 63) / 64;          // 64 x 64 output blocks per dimension
     const bool pair = d_c != nullptr;
-    int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
-    int blocks = rt().n_cu * 2;
-    if (n_batches < blocks) blocks = (int)n_batches;
+    const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
     const size_t width = (size_t)NG * NT * NT;
-    if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * NSL * width)) return rc;
-    if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
-    int64_t *pc = count ? a->d_pcounts : nullptr;
     const BasisParams &bp = a->basis->p;
     const double *coef = a->basis->d_coef;
-    const bool timed = !diff_gram_only;
-    if (timed) if (int rc = timing_begin(a)) return rc;
-    int rc;
-#define MLMC_COV_DISPATCH(KIND)                                                                                          \
-    rc = diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, pair, blocks, coef, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
-                        : launch_cov_kind<KIND, 0>(bp, T, pair, blocks, coef, d_f, d_c, d_mask, n, R, a->d_partials, pc)
-    switch (bp.kind) {
-        case MLMC_LEGENDRE: MLMC_COV_DISPATCH(MLMC_LEGENDRE); break;
-        case MLMC_MONOMIAL: MLMC_COV_DISPATCH(MLMC_MONOMIAL); break;
-        case MLMC_FOURIER: MLMC_COV_DISPATCH(MLMC_FOURIER); break;
-        default: return fail("covariance: unsupported basis kind");
-    }
-#undef MLMC_COV_DISPATCH
-    if (rc) return rc;
-    if (timed) {
-        if (int rc2 = timing_end(a)) return rc2;
-        a->launches += 1;
-        a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
-    }
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0);
-    hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, a->d_partials, blocks * NSL, NT, NG,
-                       a->RP, totals);
-    MLMC_HIP_CHECK(hipGetLastError());
-    if (count) {
-        hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
-        MLMC_HIP_CHECK(hipGetLastError());
-    }
+    for (int bi = 0; bi < NB; ++bi)
+        for (int bj = 0; bj < NB; ++bj) {
+            int blocks = rt().n_cu * ((bi != bj) ? 1 : 2);
+            if (n_batches < blocks) blocks = (int)n_batches;
+            if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * NSL * width)) return rc;
+            if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
+            const bool do_count = count && bi == 0 && bj == 0;
+            int64_t *pc = do_count ? a->d_pcounts : nullptr;
+            const bool timed = !diff_gram_only;
+            if (timed) if (int rc = timing_begin(a)) return rc;
+            int rc;
+#define MLMC_COV_DISPATCH(KIND)                                                                                               \
+    rc = diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, bi, bj, pair, blocks, coef, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
+                        : launch_cov_kind<KIND, 0>(bp, T, bi, bj, pair, blocks, coef, d_f, d_c, d_mask, n, R, a->d_partials, pc)
+            switch (bp.kind) {
+                case MLMC_LEGENDRE: MLMC_COV_DISPATCH(MLMC_LEGENDRE); break;
+                case MLMC_MONOMIAL: MLMC_COV_DISPATCH(MLMC_MONOMIAL); break;
+                case MLMC_FOURIER: MLMC_COV_DISPATCH(MLMC_FOURIER); break;
+                default: return fail("covariance: unsupported basis kind");
+            }
+#undef MLMC_COV_DISPATCH
+            if (rc) return rc;
+            if (timed) {
+                if (int rc2 = timing_end(a)) return rc2;
+                a->launches += 1;
+                a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
+            }
+            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, a->d_partials, blocks * NSL, NT, NG,
+                               a->RP, 64 * bi, 64 * bj, totals);
+            MLMC_HIP_CHECK(hipGetLastError());
+            if (do_count) {
+                hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
+                MLMC_HIP_CHECK(hipGetLastError());
+            }
+        }
     return 0;
 }
 

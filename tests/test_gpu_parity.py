@@ -360,3 +360,28 @@ def test_device_resident_inputs_and_large_property(hip):
         assert nk == n3[l] and nr == n_rm3[l]
         rms_l = np.sqrt(spo / nk) * nk
         assert close(s3[l], so, rms_l, 1e-10) and close(sp3[l], spo, None, 1e-10)
+
+
+@pytest.mark.parametrize("R", [65, 80, 128])
+def test_covariance_more_than_64_moments(hip, R):
+    """R > 64: the covariance is assembled from 64 x 64 term-window blocks (two LDS windows off the diagonal)."""
+    from mlmc_amd import Legendre, TransformedMoments
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-3.7, 3.7)
+    levels = level_arrays([1500, 901], [0.3, 0.02], 1, 7)
+    b = onp.Basis(onp.LEGENDRE, R, dom)
+    n, n_rm, s, sp = _run_accum(Legendre(R, dom), levels, mode=LevelAccumulator.COV)
+    for l, (f, c) in enumerate(levels):
+        nk, nr, so, spo = oracle_c.cov_level(b, f[0], None if c is None else c[0])
+        assert nk == n[l] and nr == n_rm[l]
+        rms = np.sqrt(spo / max(nk, 1)) * nk
+        assert close(s[l], so, rms, TOL) and close(sp[l], spo, None, TOL)
+    if R == 80:   # variance of transformed moments with more than 64 underlying moments (wide difference Gram)
+        rng = np.random.default_rng(5)
+        mat = rng.normal(size=(70, R)) / np.sqrt(R)
+        mat[0] = 0
+        mat[0, 0] = 1
+        n, n_rm, s, sp = _run_accum(TransformedMoments(Legendre(R, dom), mat), levels)
+        bt = onp.Basis(onp.LEGENDRE, R, dom, matrix=mat)
+        ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(bt, x))
+        _check_against(n, n_rm, s, sp, ref)
