@@ -63,8 +63,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("MLMC_HIP_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
@@ -146,9 +149,10 @@ def main():
         alu_peak, alu_bound, kname = FP64_MFMA_PEAK_TFLOPS, "mfma_f64", "k_cov_accum"
     step_kernel_s = (kt[0] / 1e3) / args.steps
     achieved_tflops = flops / step_kernel_s / 1e12 if step_kernel_s > 0 else 0.0
+    traffic, traffic_src = pmc_traffic_per_launch(args.config, kname, n_l, L, kt[1] // max(args.steps, 1))
     roofline = {
         "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": kname, "avg_launch_ms": round(avg_launch_ms, 5), "alg_bytes_per_launch": int(bytes_per_launch),
         "launches_per_step": kt[1] // max(args.steps, 1),
         # the kernel is fp64-ALU bound for R >= 12: the binding roof, reported beside the HBM one
@@ -171,8 +175,38 @@ def main():
         out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_stats)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def pmc_traffic_per_launch(config, kname, n_l, L, launches_per_step):
+    """HBM bytes per accumulation launch from the most recent committed rocprofv3 PMC passes of this same command
+    (profiles/rNN_pmc_config<k>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs).  FETCH_SIZE is in KB and, on
+    gfx950, counts half of a coalesced streaming read (guide, HBM section) -> read bytes = 2 * FETCH_SIZE * 1024.
+    The profiles hold per-dispatch averages per kernel instantiation; they are summed over the dispatches that make one
+    launch-equivalent of this run (one multi-level launch = all levels).  None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_config{}.json".format(config))))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        prof = json.load(f)
+    read_b = write_b = 0.0
+    n_disp = 0
+    for name, e in prof.items():
+        if kname not in name or "FETCH_SIZE_avg_per_dispatch" not in e:
+            continue
+        per_step = e.get("dispatches_fetch", 0)
+        read_b += 2.0 * e["FETCH_SIZE_avg_per_dispatch"] * 1024.0 * per_step
+        write_b += e.get("WRITE_SIZE_avg_per_dispatch", 0.0) * 1024.0 * per_step
+        n_disp += per_step
+    if n_disp == 0:
+        return None, None
+    # the profile run covered `steps_prof` estimates; normalise to one estimate, then to one launch of THIS run
+    levels_bytes = (2 * L - 1) * n_l * 8.0
+    steps_prof = max(1, round(read_b / levels_bytes))
+    per_step = (read_b + write_b) / steps_prof
+    return int(per_step / max(launches_per_step, 1)), os.path.basename(files[-1])
 
 
 def cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_stats):

@@ -385,3 +385,23 @@ def test_covariance_more_than_64_moments(hip, R):
         bt = onp.Basis(onp.LEGENDRE, R, dom, matrix=mat)
         ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(bt, x))
         _check_against(n, n_rm, s, sp, ref)
+
+
+def test_rccl_allreduce_path_single_rank(hip):
+    """The N > 1 exchange step (finalize into device buffers + torch.distributed all-reduce, backend nccl = RCCL) run
+    with one rank in a child process: bench.py with MLMC_HIP_FORCE_DIST=1 must give the same estimate."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MLMC_HIP_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["result_check"]["mean0"] == 1.0 and d["result_check"]["var0"] == 0.0
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    d0 = json.loads([l for l in ref.stdout.splitlines() if l.startswith("{")][-1])
+    assert d0["result_check"] == d["result_check"]
