@@ -31,7 +31,7 @@ CONFIGS = {
     2: dict(L=3, n_per_level=10_000_000, R=32, mode="moments",
             workload="BASELINE configs[1]: 3 levels x 1e7 synthetic samples per GPU, Legendre n_moments=32, mean+var estimate"),
     3: dict(L=5, n_per_level=10_000_000, R=64, mode="cov",
-            workload="BASELINE configs[2]: 5 levels x 1e7 synthetic samples per GPU, Legendre n_moments=64, moment covariance mean+var"),
+            workload="BASELINE configs[2]: 5 levels x 1e7 synthetic samples per GPU, Legendre n_moments=64, moment covariance mean+var + level-variance regression + n_samples re-allocation"),
 }
 
 
@@ -57,6 +57,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: native libraries (the RCCL banner, amdgpu notices) write to fd 1 directly,
+    # so fd 1 points at stderr until the result is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -66,6 +72,7 @@ def main():
     if world > 1 or os.environ.get("MLMC_HIP_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL logs to stdout by default; stdout carries the JSON line
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
@@ -89,6 +96,14 @@ def main():
     data = [synth_device(l, n_l, steps, 1234 + 1000 * rank, dev) for l in range(L)]
     torch.cuda.synchronize()
 
+    # configs[2] also re-allocates the samples per level: level variances of the moments (a second, cheap accumulation
+    # pass) -> log-quadratic regression over the levels -> n_samples for a target variance (estimator.py:56-74,366-385)
+    acc_mom = LevelAccumulator(fn, L, LevelAccumulator.MOMENTS) if cfg["mode"] == "cov" else None
+    n_ops = [(1.0 / h) ** 2 * np.log(max(1.0 / h, 2.0)) for h in steps]      # synth_simulation.py:133-134
+    from mlmc_amd.estimator import Estimate, estimate_n_samples_for_target_variance
+    regress = Estimate(None, None, fn)._all_moments_variance_regression
+    extra = {}
+
     def one_estimate():
         acc.reset()
         for l in range(L):
@@ -98,6 +113,14 @@ def main():
         mean = np.sum(l_means, axis=0)
         with np.errstate(all="ignore"):
             var = np.sum(l_vars / n[:, None], axis=0)
+        if acc_mom is not None:
+            acc_mom.reset()
+            for l in range(L):
+                acc_mom.push(l, data[l][0], data[l][1])
+            n2, _, s2, sp2 = acc_mom.finalize()
+            _, raw_vars = level_stats(n2, s2, sp2)
+            reg_vars = regress(raw_vars, np.array(steps))
+            extra["n_estimated"] = [int(v) for v in estimate_n_samples_for_target_variance(1e-6, reg_vars, n_ops, n_levels=L)]
         return n, n_rm, mean, var
 
     def sync():
@@ -113,7 +136,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = one_estimate()
-        ms, launches, nbytes = acc.kernel_time()
+        ms, launches, nbytes = acc.kernel_time()     # the dominant kernel (config 3: the covariance kernel)
         kt[0] += ms
         kt[1] += launches
         kt[2] += nbytes
@@ -169,12 +192,17 @@ def main():
         "roofline": roofline,
         "result_check": {"mean0": float(np.ravel(mean)[0]), "var0": float(np.ravel(var)[0]), "n_removed": [int(v) for v in n_rm]},
     }
+    out["result_check"].update(extra)
 
     # ---- CPU baseline + parity gate on a bounded sample (rank 0, N = 1 only) ---------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_stats)
+    if dist.is_initialized():
+        dist.barrier()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -93,6 +93,9 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
  * Outputs in host or device memory (device: for an RCCL all-reduce over ranks before the host reads them).
  * Synchronises the stream; idempotent. */
 int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, double *sp, int mem_kind);
+/* Same results in ONE fp64 buffer [n(L) | n_rm(L) | s(L*K) | sp(L*K)] (counts as exact doubles): a single packed
+ * all-reduce (RCCL) then carries everything a multi-GPU estimate has to exchange. */
+int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind);
 /* HIP-event time (ms) and launch count of the dominant accumulation kernel since create/reset
  * (needs mlmc_init flag bit0); also the algorithmic HBM bytes those launches had to read. */
 int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes);

@@ -227,7 +227,7 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     }
     const size_t tot = (size_t)n_levels * n_comp * a->int_width;
     a->state_bytes = sizeof(double) * tot + sizeof(int64_t) * 2 * n_levels + 64;
-    a->out_bytes = sizeof(int64_t) * 2 * n_levels + 2 * sizeof(double) * (size_t)n_levels * a->K;
+    a->out_bytes = (sizeof(int64_t) + sizeof(double)) * 2 * n_levels + 2 * sizeof(double) * (size_t)n_levels * a->K;
     if (hipMalloc(&a->d_state, a->state_bytes) != hipSuccess || hipMalloc(&a->d_out, a->out_bytes) != hipSuccess ||
         hipHostMalloc(&a->h_out, a->out_bytes, hipHostMallocDefault) != hipSuccess) {
         mlmc_accum_destroy(a);
@@ -237,7 +237,8 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->d_counts = (int64_t *)(a->d_totals + tot);
     a->d_ticket = (unsigned *)(a->d_counts + 2 * (size_t)n_levels);
     a->d_out_n = (int64_t *)a->d_out;
-    a->d_out_s = (double *)(a->d_out_n + 2 * (size_t)n_levels);
+    a->d_out_nd = (double *)(a->d_out_n + 2 * (size_t)n_levels);
+    a->d_out_s = a->d_out_nd + 2 * (size_t)n_levels;
     a->d_out_sp = a->d_out_s + (size_t)n_levels * a->K;
     *out = a;
     return mlmc_accum_reset(a);
@@ -349,12 +350,26 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
         MLMC_HIP_CHECK(hipMemcpyAsync(a->h_out, a->d_out, a->out_bytes, hipMemcpyDeviceToHost, st));
         MLMC_HIP_CHECK(hipStreamSynchronize(st));
         const int64_t *hn = (const int64_t *)a->h_out;
-        const double *hs = (const double *)(hn + 2 * (size_t)L);
+        const double *hs = (const double *)(hn + 2 * (size_t)L) + 2 * (size_t)L;
         std::memcpy(n, hn, sizeof(int64_t) * L);
         std::memcpy(n_rm, hn + L, sizeof(int64_t) * L);
         std::memcpy(s, hs, sizeof(double) * nk);
         std::memcpy(sp, hs + nk, sizeof(double) * nk);
     }
+    return timing_collect(a);
+}
+
+int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind) {
+    if (need_runtime()) return 1;
+    if (!a || !packed) return fail("mlmc_accum_finalize_packed: null argument");
+    hipStream_t st = rt().stream;
+    if (a->mode == MLMC_MODE_MOMENTS)
+        if (int rcf = flush_moments(a)) return rcf;
+    int rc = (a->mode == MLMC_MODE_MOMENTS) ? launch_moments_finalize(a) : launch_cov_finalize(a);
+    if (rc) return rc;
+    const size_t bytes = sizeof(double) * (2 * (size_t)a->n_levels + 2 * (size_t)a->n_levels * a->K);
+    MLMC_HIP_CHECK(hipMemcpyAsync(packed, a->d_out_nd, bytes, mem_kind == MLMC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    MLMC_HIP_CHECK(hipStreamSynchronize(st));
     return timing_collect(a);
 }
 

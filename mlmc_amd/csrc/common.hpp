@@ -80,10 +80,10 @@ struct mlmc_accum {
     int64_t *d_pcounts = nullptr; size_t pcounts_cap = 0;
     double *d_stage_f = nullptr, *d_stage_c = nullptr; size_t stage_cap = 0;
     uint8_t *d_mask = nullptr; size_t mask_cap = 0;
-    void *d_out = nullptr;        // finalize outputs, one allocation: n[L] | n_rm[L] | s[L*K] | sp[L*K]
+    void *d_out = nullptr;        // finalize outputs, one allocation: n[L] | n_rm[L] (int64) | n, n_rm as fp64 [2L] | s[L*K] | sp[L*K]
     size_t out_bytes = 0;
     void *h_out = nullptr;        // pinned host mirror of d_out
-    double *d_out_s = nullptr, *d_out_sp = nullptr; int64_t *d_out_n = nullptr;
+    double *d_out_s = nullptr, *d_out_sp = nullptr, *d_out_nd = nullptr; int64_t *d_out_n = nullptr;
     // timing
     std::vector<hipEvent_t> ev;   // pairs (start, stop)
     size_t ev_used = 0;

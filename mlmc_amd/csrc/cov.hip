@@ -289,12 +289,15 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
 // out_s[lc][i][j] = 1/2 c_i c_j (G0_ij + G0_ji);  out_sp[lc][i][j] = 1/4 c_i^2 c_j^2 (G1_ij + G1_ji + 2 G2_ij)
 __global__ void k_cov_finalize(const double *__restrict__ totals, const double *__restrict__ scale_c, int R, int RP,
                                int64_t int_width, double *__restrict__ out_s, double *__restrict__ out_sp,
-                               const int64_t *__restrict__ counts, int n_levels, int64_t *__restrict__ out_n) {
+                               const int64_t *__restrict__ counts, int n_levels, int64_t *__restrict__ out_n,
+                               double *__restrict__ out_nd) {
     const int lc = blockIdx.y;
     if (lc == 0 && blockIdx.x == 0)
         for (int l = threadIdx.x; l < n_levels; l += blockDim.x) {
             out_n[l] = counts[2 * l];
             out_n[n_levels + l] = counts[2 * l + 1];
+            out_nd[l] = (double)counts[2 * l];               // exact below 2^53: lets one fp64 all-reduce carry the counts
+            out_nd[n_levels + l] = (double)counts[2 * l + 1];
         }
     const double *G0 = totals + (int64_t)lc * int_width;
     const double *G1 = G0 + (int64_t)RP * RP;
@@ -312,7 +315,7 @@ int launch_cov_finalize(mlmc_accum *a) {
     const int n_lc = a->n_levels * a->n_comp;
     const int R = a->R;
     hipLaunchKernelGGL(k_cov_finalize, dim3((R * R + 255) / 256, n_lc), dim3(256), 0, rt().stream, a->d_totals, a->basis->d_scale, R,
-                       a->RP, a->int_width, a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n);
+                       a->RP, a->int_width, a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n, a->d_out_nd);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -463,13 +463,16 @@ int launch_moments_accum(mlmc_accum *a, int level, int comp, const double *d_f, 
 __global__ void k_moments_finalize(const double *__restrict__ totals, const double *__restrict__ scale_c,
                                    const double *__restrict__ T, int R, int RP, int Rout, int has_T, int64_t int_width,
                                    int n_lc, double *__restrict__ out_s, double *__restrict__ out_sp,
-                                   const int64_t *__restrict__ counts, int n_levels, int64_t *__restrict__ out_n) {
+                                   const int64_t *__restrict__ counts, int n_levels, int64_t *__restrict__ out_n,
+                               double *__restrict__ out_nd) {
     const int lc = blockIdx.x;   // (level, comp)
     if (lc >= n_lc) return;
     if (lc == 0)
         for (int l = threadIdx.x; l < n_levels; l += blockDim.x) {   // (kept, removed) pairs -> n[L], n_rm[L]
             out_n[l] = counts[2 * l];
             out_n[n_levels + l] = counts[2 * l + 1];
+            out_nd[l] = (double)counts[2 * l];               // exact below 2^53: lets one fp64 all-reduce carry the counts
+            out_nd[n_levels + l] = (double)counts[2 * l + 1];
         }
     const double *tot = totals + (int64_t)lc * int_width;
     for (int j = threadIdx.x; j < Rout; j += blockDim.x) {
@@ -499,7 +502,7 @@ int launch_moments_finalize(mlmc_accum *a) {
     const int n_lc = a->n_levels * a->n_comp;
     hipLaunchKernelGGL(k_moments_finalize, dim3(n_lc), dim3(128), 0, rt().stream, a->d_totals, a->basis->d_scale,
                        a->basis->d_matrix, a->R, a->RP, a->Rout, a->basis->out_size > 0 ? 1 : 0, a->int_width, n_lc,
-                       a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n);
+                       a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n, a->d_out_nd);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -120,12 +120,9 @@ class LevelAccumulator:
         L, K = self.n_levels, self.K
         on_gpu = dist.get_backend(group) == "nccl"
         dev = torch.device("cuda", _lib._bound_device) if on_gpu else torch.device("cpu")
-        counts = torch.empty(2 * L, dtype=torch.int64, device=dev)
-        sums = torch.empty(2 * L * K, dtype=torch.float64, device=dev)
-        _lib.check(_lib.lib().mlmc_accum_finalize(self._h, _lib.ptr(counts[:L]), _lib.ptr(counts[L:]), _lib.ptr(sums[:L * K]),
-                                                  _lib.ptr(sums[L * K:]), _lib.DEVICE if on_gpu else _lib.HOST))
-        counts, sums = allreduce_partials(counts, sums, group)
-        return counts[:L].copy(), counts[L:].copy(), sums[:L * K].reshape(L, K).copy(), sums[L * K:].reshape(L, K).copy()
+        packed = torch.empty(2 * L + 2 * L * K, dtype=torch.float64, device=dev)     # n | n_rm | s | sp
+        _lib.check(_lib.lib().mlmc_accum_finalize_packed(self._h, _lib.ptr(packed), _lib.DEVICE if on_gpu else _lib.HOST))
+        return unpack_partials(allreduce_partials(packed, group), L, K)
 
     def kernel_time(self):
         """(ms, launches, algorithmic bytes) of the accumulation kernels since create/reset (needs FLAG_TIMING)."""
@@ -136,14 +133,21 @@ class LevelAccumulator:
         return ms.value, launches.value, nbytes.value
 
 
-def allreduce_partials(counts, sums, group=None):
-    """The only exchange step of the path: one packed all-reduce (sum) of the int64 counts and one of the
-    fp64 partial sums over the ranks (RCCL over xGMI with backend "nccl"; "gloo" in CPU tests).
-    Takes torch tensors (device or host), returns NumPy arrays."""
+def allreduce_partials(packed, group=None):
+    """The only exchange step of the path: ONE all-reduce (sum) of the packed fp64 partials
+    [n(L) | n_rm(L) | s(L*K) | sp(L*K)] over the ranks (RCCL over xGMI with backend "nccl"; "gloo" in CPU tests).
+    The sample counts travel as doubles (exact below 2^53).  Takes a torch tensor, returns a NumPy array."""
     import torch.distributed as dist
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-    return counts.cpu().numpy(), sums.cpu().numpy()
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return packed.cpu().numpy()
+
+
+def unpack_partials(packed, L, K):
+    n = np.rint(packed[:L]).astype(np.int64)
+    n_rm = np.rint(packed[L:2 * L]).astype(np.int64)
+    s = packed[2 * L:2 * L + L * K].reshape(L, K).copy()
+    sp = packed[2 * L + L * K:].reshape(L, K).copy()
+    return n, n_rm, s, sp
 
 
 def shard_bounds(n, rank, world_size):

@@ -26,26 +26,23 @@ def _worker(rank, world, port, N, steps, R, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from mlmc_amd.engine import allreduce_partials, level_stats, shard_bounds
+        from mlmc_amd.engine import allreduce_partials, level_stats, shard_bounds, unpack_partials
         dom = (-3.7190164854556804, 3.7190164854556804)
         b = onp.Basis(onp.LEGENDRE, R, dom)
         levels = level_arrays(N, steps, 1, 13)
         L = len(N)
-        counts = torch.zeros(2 * L, dtype=torch.int64)
-        sums = torch.zeros(2 * L * R, dtype=torch.float64)
+        packed = torch.zeros(2 * L + 2 * L * R, dtype=torch.float64)      # n | n_rm | s | sp
         for l, (f, c) in enumerate(levels):
             lo, hi = shard_bounds(f.shape[1], rank, world)
             x = f[:, lo:hi, None] if c is None else np.stack([f[:, lo:hi], c[:, lo:hi]], axis=-1)
             rows = onp.moments_rows(b, x)
             chunk, n_mask = onp.mask_nan_samples(rows)
             d = chunk[:, :, 0] if l == 0 else chunk[:, :, 0] - chunk[:, :, 1]
-            counts[l] = chunk.shape[1]
-            counts[L + l] = n_mask
-            sums[l * R:(l + 1) * R] = torch.from_numpy(d.sum(axis=1))
-            sums[(L + l) * R:(L + l + 1) * R] = torch.from_numpy((d ** 2).sum(axis=1))
-        c_np, s_np = allreduce_partials(counts, sums)
-        n, n_rm = c_np[:L], c_np[L:]
-        s, sp = s_np[:L * R].reshape(L, R), s_np[L * R:].reshape(L, R)
+            packed[l] = chunk.shape[1]
+            packed[L + l] = n_mask
+            packed[2 * L + l * R:2 * L + (l + 1) * R] = torch.from_numpy(d.sum(axis=1))
+            packed[2 * L + (L + l) * R:2 * L + (L + l + 1) * R] = torch.from_numpy((d ** 2).sum(axis=1))
+        n, n_rm, s, sp = unpack_partials(allreduce_partials(packed), L, R)
         l_means, l_vars = level_stats(n, s, sp)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), n=n, n_rm=n_rm, l_means=l_means, l_vars=l_vars)
     finally:
