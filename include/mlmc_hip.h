@@ -61,6 +61,9 @@ typedef struct {
  * accumulation kernels (read back with mlmc_accum_kernel_time). */
 int mlmc_init(int device, int flags);
 void mlmc_shutdown(void);
+/* Run all later work on the caller's HIP stream (e.g. the stream RCCL collectives are enqueued on), so that
+ * mlmc_accum_finalize_packed(..., MLMC_DEVICE) followed by an all-reduce needs no host synchronisation in between. */
+int mlmc_set_stream(void *hip_stream);
 const char *mlmc_last_error(void);
 int mlmc_abi_version(void);
 /* name[<=256], CU count, wavefront size, total HBM bytes of the bound device */
@@ -94,7 +97,8 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
  * Synchronises the stream; idempotent. */
 int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, double *sp, int mem_kind);
 /* Same results in ONE fp64 buffer [n(L) | n_rm(L) | s(L*K) | sp(L*K)] (counts as exact doubles): a single packed
- * all-reduce (RCCL) then carries everything a multi-GPU estimate has to exchange. */
+ * all-reduce (RCCL) then carries everything a multi-GPU estimate has to exchange.  With MLMC_DEVICE the call is
+ * asynchronous (stream-ordered); with MLMC_HOST it synchronises. */
 int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind);
 /* HIP-event time (ms) and launch count of the dominant accumulation kernel since create/reset
  * (needs mlmc_init flag bit0); also the algorithmic HBM bytes those launches had to read. */

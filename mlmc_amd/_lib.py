@@ -47,6 +47,7 @@ _vp = C.c_void_p
 SIGNATURES = {
     "mlmc_init": (C.c_int, [C.c_int, C.c_int]),
     "mlmc_shutdown": (None, []),
+    "mlmc_set_stream": (C.c_int, [_vp]),
     "mlmc_last_error": (C.c_char_p, []),
     "mlmc_abi_version": (C.c_int, []),
     "mlmc_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _ip]),
@@ -118,6 +119,12 @@ def lib():
     if _bound_device is None:
         return init()
     return _lib
+
+
+def use_torch_stream():
+    """Enqueue all kernels on torch's current CUDA/HIP stream (the one torch.distributed collectives use)."""
+    import torch
+    check(lib().mlmc_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
 def device_info():

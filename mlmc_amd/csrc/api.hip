@@ -91,6 +91,7 @@ int mlmc_init(int device, int flags) {
     if (std::strncmp(r.prop.gcnArchName, "gfx950", 6) != 0)
         return fail(std::string("mlmc_init: kernels are built for gfx950 only, device is ") + r.prop.gcnArchName);
     MLMC_HIP_CHECK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    r.own_stream = true;
     r.device = device;
     r.flags = flags;
     r.n_cu = r.prop.multiProcessorCount;
@@ -98,11 +99,21 @@ int mlmc_init(int device, int flags) {
     return 0;
 }
 
+int mlmc_set_stream(void *stream) {
+    Runtime &r = rt();
+    if (!r.ready) return fail("mlmc_init has not been called (no HIP device bound)");
+    MLMC_HIP_CHECK(hipStreamSynchronize(r.stream));
+    if (r.own_stream) (void)hipStreamDestroy(r.stream);
+    r.stream = (hipStream_t)stream;      // NULL = the legacy default stream
+    r.own_stream = false;
+    return 0;
+}
+
 void mlmc_shutdown(void) {
     Runtime &r = rt();
     if (!r.ready) return;
     (void)hipStreamSynchronize(r.stream);
-    (void)hipStreamDestroy(r.stream);
+    if (r.own_stream) (void)hipStreamDestroy(r.stream);
     r.stream = nullptr;
     r.ready = false;
     r.device = -1;
@@ -369,12 +380,17 @@ int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind) {
     if (rc) return rc;
     const size_t bytes = sizeof(double) * (2 * (size_t)a->n_levels + 2 * (size_t)a->n_levels * a->K);
     MLMC_HIP_CHECK(hipMemcpyAsync(packed, a->d_out_nd, bytes, mem_kind == MLMC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    if (mem_kind == MLMC_DEVICE) return 0;   // stream-ordered: the caller's collective on the same stream needs no host sync
     MLMC_HIP_CHECK(hipStreamSynchronize(st));
     return timing_collect(a);
 }
 
 int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes) {
     if (!a) return fail("mlmc_accum_kernel_time: null argument");
+    if (a->ev_used) {   // events of an asynchronous finalize: wait for the last one, then collect
+        MLMC_HIP_CHECK(hipEventSynchronize(a->ev[a->ev_used - 1]));
+        if (int rc = timing_collect(a)) return rc;
+    }
     if (ms) *ms = a->ms_total;
     if (launches) *launches = a->launches;
     if (alg_bytes) *alg_bytes = a->alg_bytes;

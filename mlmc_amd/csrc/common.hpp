@@ -29,6 +29,7 @@ struct Runtime {
     int flags = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = false;
     hipDeviceProp_t prop;
 };
 Runtime &rt();

@@ -10,7 +10,6 @@
 // recurrences for fine and coarse kept in registers, per-lane fp64 accumulators for sum(d) and sum(d^2),
 // wave shuffles + LDS for the block partial, and a fixed-order second kernel for the grid reduction
 // (bitwise reproducible run to run).
-#include <cstdlib>
 #include <cstring>
 
 #include "device_basis.hpp"
@@ -392,9 +391,7 @@ int flush_moments(mlmc_accum *a) {
         const int resident = rt().n_cu * per_cu;
         // blocks per segment in proportion to its work: 7 fp64 instructions per pair and term, 4 at level 0 plus the
         // per-sample overhead (measured time ratio pair : level-0 = 1.5 at R = 32)
-        const double W_PAIR = 7.0;
-        double W_SINGLE = 4.3;
-        if (const char *e = getenv("MLMC_HIP_DEV_WSINGLE")) W_SINGLE = atof(e);   // development knob
+        constexpr double W_PAIR = 7.0, W_SINGLE = 4.3;
         double wsum = 0.0;
         for (const PendingSeg &p : a->pending) wsum += (double)p.n * (p.coarse ? W_PAIR : W_SINGLE);
         SegTable tab;

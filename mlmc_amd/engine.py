@@ -119,6 +119,11 @@ class LevelAccumulator:
         import torch.distributed as dist
         L, K = self.n_levels, self.K
         on_gpu = dist.get_backend(group) == "nccl"
+        if on_gpu and not getattr(_lib, "_on_torch_stream", False):
+            # one stream for kernels and collectives: finalize -> all-reduce is stream-ordered, no host sync in between
+            torch.cuda.set_device(_lib._bound_device)
+            _lib.use_torch_stream()
+            _lib._on_torch_stream = True
         dev = torch.device("cuda", _lib._bound_device) if on_gpu else torch.device("cpu")
         packed = torch.empty(2 * L + 2 * L * K, dtype=torch.float64, device=dev)     # n | n_rm | s | sp
         _lib.check(_lib.lib().mlmc_accum_finalize_packed(self._h, _lib.ptr(packed), _lib.DEVICE if on_gpu else _lib.HOST))

@@ -1,10 +1,10 @@
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from mlmc_amd import _lib, Legendre, TransformedMoments
 from mlmc_amd.tool import simple_distribution as sd
 _lib.init(0)
-g6 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G6_maxent.npz"))
+g6 = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "G6_maxent.npz"))
 for key in ("norm12_R7", "norm12_R21", "norm12_R41", "lognorm_R41"):
     R = int(key.split("_R")[1])
     dom = tuple(g6[key + "_domain"])
