@@ -177,6 +177,194 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Diagonal 64 x 64 blocks (T = 4, one term window): wave-specialised variant that uses the symmetry of
+// G2 = (D.S)^T (D.S) (and, at level 0, of G0 = F^T F and G1 = (F.F)^T (F.F); in MODE 1 of G = D^T D).
+// Only the 10 upper tiles of a symmetric matrix are computed, spread 3 / 3 / 2 / 2 over the four waves; the mirrored
+// tile is written with the partials.  MFMAs per 4 samples and wave: 11 / 11 / 10 / 10 instead of 12 (pair levels),
+// 6 / 6 / 4 / 4 instead of 8 (level 0), 3 / 3 / 2 / 2 instead of 4 (MODE 1).
+// ------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int sym_n(int w) { return w < 2 ? 3 : 2; }
+__host__ __device__ constexpr int sym_i(int w, int t) { return (w == 3 && t == 1) ? 0 : w; }
+__host__ __device__ constexpr int sym_j(int w, int t) {
+    // w0: (0,0) (0,1) (0,2)   w1: (1,1) (1,2) (1,3)   w2: (2,2) (2,3)   w3: (3,3) (0,3)
+    return (w == 3) ? 3 : w + t;
+}
+
+template <int KIND, bool PAIR, int MODE, int BD, int W>
+__device__ __forceinline__ void cov_t4_body(const BasisParams &bp, const double *__restrict__ coef,
+                                            const double *__restrict__ fine, const double *__restrict__ coarse,
+                                            const uint8_t *__restrict__ mask, int64_t n, double *__restrict__ partials,
+                                            int64_t *__restrict__ pcounts, double *__restrict__ lds_f,
+                                            double *__restrict__ lds_c, int (*ldc)[2]) {
+    constexpr int NT = 64;
+    constexpr int TA = 64 * BD;
+    constexpr int N_EVAL = TA + NT;
+    constexpr int NS = sym_n(W);
+    constexpr int NFULL = (MODE == 0 && PAIR) ? 2 : 0;     // G0, G1: full row W
+    constexpr int NSYMM = (MODE == 0 && !PAIR) ? 2 : 1;    // symmetric matrices handled through the tile list
+    const int lane = threadIdx.x & 63;
+
+    v4f64 accf[NFULL > 0 ? NFULL : 1][4];
+    v4f64 accs[NSYMM][NS];
+#pragma unroll
+    for (int g = 0; g < (NFULL > 0 ? NFULL : 1); ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accf[g][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < NSYMM; ++g)
+#pragma unroll
+        for (int t = 0; t < NS; ++t) accs[g][t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    constexpr bool evaluator = W < (PAIR ? 2 : 1);
+    const int samp = PAIR ? (W * 32 + (lane & 31)) : lane;
+    const bool is_coarse = PAIR && (lane >> 5);
+    const double *__restrict__ src = is_coarse ? coarse : fine;
+    double *__restrict__ dst = is_coarse ? lds_c : lds_f;
+    int n_keep = 0, n_rm = 0;
+
+    const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
+    int64_t batch = blockIdx.x;
+    double xv = 0.0;
+    uint8_t mv = 1;
+    if (evaluator && batch < n_batches) {
+        int64_t idx = batch * COV_BATCH + samp;
+        if (idx < n) { xv = src[idx]; if (mask) mv = mask[idx]; }
+    }
+    for (; batch < n_batches; batch += gridDim.x) {
+        if (evaluator) {
+            const int64_t idx = batch * COV_BATCH + samp;
+            const bool valid = idx < n;
+            bool keep;
+            double t = transform_value(bp, xv, keep);
+            keep = keep && valid && (mv != 0);
+            if (PAIR) {
+                const int other = __shfl_xor((int)keep, 32, 64);
+                keep = keep && (other != 0);
+            }
+            if (!is_coarse) { n_keep += (int)keep; n_rm += (int)(valid && !keep); }
+            const int64_t nidx = (batch + gridDim.x) * COV_BATCH + samp;
+            if (nidx < n) { xv = src[nidx]; if (mask) mv = mask[nidx]; }
+            TermGen<KIND> g;
+            g.init(keep ? t : 0.0, keep ? 1.0 : 0.0);
+#pragma unroll
+            for (int i = 0; i < N_EVAL; ++i) {
+                const double q = g.next(i, coef);
+                if (i >= TA) dst[(i - TA) * COV_LDS_STRIDE + samp] = q;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < COV_BATCH / 4; ++ks) {
+            const int col = 4 * ks + (lane >> 4);
+            double d[4], sm[4];
+#pragma unroll
+            for (int J = 0; J < 4; ++J) {
+                const int row = 16 * J + (lane & 15);
+                const double f = lds_f[row * COV_LDS_STRIDE + col];
+                d[J] = f;
+                sm[J] = f;
+                if (PAIR) {
+                    const double c = lds_c[row * COV_LDS_STRIDE + col];
+                    d[J] = f - c;
+                    sm[J] = f + c;
+                }
+            }
+            if (MODE == 0 && PAIR) {
+                const double dw2 = d[W] * d[W];
+                double ds[4];
+#pragma unroll
+                for (int J = 0; J < 4; ++J) {
+                    accf[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[W], sm[J], accf[0][J], 0, 0, 0);
+                    accf[1][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(dw2, sm[J] * sm[J], accf[1][J], 0, 0, 0);
+                    ds[J] = d[J] * sm[J];
+                }
+#pragma unroll
+                for (int t = 0; t < NS; ++t)
+                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ds[sym_i(W, t)], ds[sym_j(W, t)], accs[0][t], 0, 0, 0);
+            } else if (MODE == 0) {   // level 0: F^T F and (F.F)^T (F.F), both symmetric
+                double f2[4];
+#pragma unroll
+                for (int J = 0; J < 4; ++J) f2[J] = d[J] * d[J];
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[sym_i(W, t)], d[sym_j(W, t)], accs[0][t], 0, 0, 0);
+                    accs[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[sym_i(W, t)], f2[sym_j(W, t)], accs[1][t], 0, 0, 0);
+                }
+            } else {                  // MODE 1: D^T D
+#pragma unroll
+                for (int t = 0; t < NS; ++t)
+                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[sym_i(W, t)], d[sym_j(W, t)], accs[0][t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- partial tiles: one row per block, columns [g][row][col]; symmetric tiles are mirrored here ----
+    constexpr int NGOUT = (MODE == 0) ? 3 : 1;
+    double *__restrict__ prow = partials + (int64_t)blockIdx.x * (NGOUT * NT * NT);
+    const int r0 = lane >> 4, c0 = lane & 15;
+    if (MODE == 0 && PAIR) {
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * W + r0 + 4 * r, col = 16 * J + c0;
+                prow[0 * NT * NT + row * NT + col] = accf[0][J][r];
+                prow[1 * NT * NT + row * NT + col] = accf[1][J][r];
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * sym_i(W, t) + r0 + 4 * r, col = 16 * sym_j(W, t) + c0;
+            if (MODE == 0 && PAIR) {
+                prow[2 * NT * NT + row * NT + col] = accs[0][t][r];
+                if (sym_i(W, t) != sym_j(W, t)) prow[2 * NT * NT + col * NT + row] = accs[0][t][r];
+            } else if (MODE == 0) {   // level 0: G0 = F^T F; G1 = G2 = (F.F)^T (F.F)
+                prow[0 * NT * NT + row * NT + col] = accs[0][t][r];
+                prow[1 * NT * NT + row * NT + col] = accs[1][t][r];
+                prow[2 * NT * NT + row * NT + col] = accs[1][t][r];
+                if (sym_i(W, t) != sym_j(W, t)) {
+                    prow[0 * NT * NT + col * NT + row] = accs[0][t][r];
+                    prow[1 * NT * NT + col * NT + row] = accs[1][t][r];
+                    prow[2 * NT * NT + col * NT + row] = accs[1][t][r];
+                }
+            } else {
+                prow[row * NT + col] = accs[0][t][r];
+                if (sym_i(W, t) != sym_j(W, t)) prow[col * NT + row] = accs[0][t][r];
+            }
+        }
+    if (pcounts) {
+        n_keep = wave_sum_i(n_keep);
+        n_rm = wave_sum_i(n_rm);
+        if (lane == 0 && W < 2) { ldc[W][0] = n_keep; ldc[W][1] = n_rm; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            int v = ldc[0][threadIdx.x] + (PAIR ? ldc[1][threadIdx.x] : 0);
+            pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = v;
+        }
+    }
+}
+
+template <int KIND, bool PAIR, int MODE, int BD>
+__global__ __launch_bounds__(256, 2) void k_cov_accum_t4(BasisParams bp, const double *__restrict__ coef,
+                                                         const double *__restrict__ fine, const double *__restrict__ coarse,
+                                                         const uint8_t *__restrict__ mask, int64_t n, int R,
+                                                         double *__restrict__ partials, int64_t *__restrict__ pcounts) {
+    __shared__ double lds_f[64 * COV_LDS_STRIDE];
+    __shared__ double lds_c[PAIR ? 64 * COV_LDS_STRIDE : 1];
+    __shared__ int ldc[2][2];
+    (void)R;
+    switch (threadIdx.x >> 6) {   // every wave runs its own specialisation (same barrier count in all of them)
+        case 0: cov_t4_body<KIND, PAIR, MODE, BD, 0>(bp, coef, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
+        case 1: cov_t4_body<KIND, PAIR, MODE, BD, 1>(bp, coef, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
+        case 2: cov_t4_body<KIND, PAIR, MODE, BD, 2>(bp, coef, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
+        default: cov_t4_body<KIND, PAIR, MODE, BD, 3>(bp, coef, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
+    }
+}
+
 // totals[g][row][col] (leading dimension RP) += sum over partial rows, fixed order.
 __global__ __launch_bounds__(1024) void k_reduce_cov(const double *__restrict__ partials, int nrows, int NT, int NG, int RP,
                                                     int roff, int coff, double *__restrict__ totals) {
@@ -210,6 +398,14 @@ template <int KIND, int T, int MODE, int BI, int BJ>
 static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, const double *coef, const double *d_f, const double *d_c,
                         const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
     hipStream_t st = rt().stream;
+    if constexpr (T == 4 && BI == BJ) {   // diagonal 64 x 64 block: symmetric, wave-specialised kernel
+        if (pair)
+            hipLaunchKernelGGL((k_cov_accum_t4<KIND, true, MODE, BI>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+        else
+            hipLaunchKernelGGL((k_cov_accum_t4<KIND, false, MODE, BI>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+        MLMC_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (pair)
         hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE, BI, BJ>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
     else
