@@ -65,9 +65,19 @@ class Estimate:
         return self._all_moments_variance_regression(raw_vars, sim_steps), self._sample_storage.get_n_ops()
 
     def _all_moments_variance_regression(self, raw_vars, sim_steps):
-        reg_vars = np.array(raw_vars, dtype=np.float64, copy=True)
-        for m in range(1, reg_vars.shape[1]):
-            reg_vars[:, m] = self._moment_variance_regression(raw_vars[:, m], sim_steps)
+        """Per-moment regression of the level variances (reference: :87-93), all moments in ONE least-squares solve with
+        several right-hand sides (the design matrix [1, log h, log^2 h] is the same for every moment)."""
+        raw_vars = np.asarray(raw_vars, dtype=np.float64)
+        reg_vars = np.array(raw_vars, copy=True)
+        n_levels = raw_vars.shape[0]
+        if n_levels >= 3:
+            cols = [m for m in range(1, raw_vars.shape[1]) if not np.allclose(raw_vars[:, m], 0)]
+            if cols:
+                log_h = np.log(np.asarray(sim_steps, dtype=np.float64)[1:])
+                design = np.stack([np.ones(n_levels - 1), log_h, log_h ** 2], axis=1)
+                with np.errstate(all="ignore"):
+                    params = np.linalg.lstsq(design, np.log(raw_vars[1:][:, cols]), rcond=None)[0]
+                    reg_vars[1:, cols] = np.exp(design @ params)
         assert np.allclose(reg_vars[:, 0], 0.0)
         return reg_vars
 
@@ -104,7 +114,10 @@ class Estimate:
                                              n_levels=self._sample_storage.get_n_levels(), sample_vector=sample_vector)
         bs_mean, bs_var, bs_l_means, bs_l_vars = [], [], [], []
         for _ in range(n_subsamples):
-            sub = self.quantity.select(self.quantity.subsample(sample_vec=sample_vector))
+            # The reference writes quantity.select(quantity.subsample(...)) here (estimator.py:186), which indexes the
+            # chunk with the picked *values* and raises IndexError; its own test (test_quantity_concept.py:630-648) uses
+            # the sub-sampled quantity directly, as done here.
+            sub = self.quantity.subsample(sample_vec=sample_vector)
             q_mean = qe.estimate_mean(qe.moments(sub, moments_fn=moments_fn, mom_at_bottom=False))
             bs_mean.append(q_mean.mean)
             bs_var.append(q_mean.var)

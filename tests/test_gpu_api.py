@@ -257,3 +257,52 @@ def test_old_distribution_solver(hip):
             got = d.density(xg)
             assert np.all(np.isfinite(got))
             assert np.max(np.abs(got - ref)) < 2e-2 * np.max(ref), (key, np.max(np.abs(got - ref)), np.max(ref))
+
+
+def test_bootstrap_and_subsample(hip):
+    """est_bootstrap (estimator.py:171-205): hypergeometric sub-sampling over chunks + moments 'on the surface'.  The
+    reference draws from an unseeded module-level RNG (quantity.py:11), so parity is statistical only."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate
+    from mlmc_amd.quantity import quantity as qmod
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    qmod.RNG = np.random.default_rng(123)
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    steps = [0.5, 0.07, 0.01]
+    N = [4000, 1500, 600]
+    levels = level_arrays(N, steps, 1, 0)
+    st = _storage(levels, steps, _scalar_spec(), chunk_size=1000)
+    q = make_root_quantity(st, _scalar_spec())['q'][1]['0'][0, 0]
+    fn = Legendre(6, dom)
+    est = Estimate(q, st, fn)
+    full_mean, full_var = est.estimate_moments()
+    sample_vec = [400, 150, 60]
+    est.est_bootstrap(n_subsamples=20, sample_vector=sample_vec)
+    assert est.mean_bs_mean.shape == (6,) and est.mean_bs_l_vars.shape == (3, 6)
+    assert est.mean_bs_mean[0] == 1.0 and np.all(est.var_bs_mean >= 0)
+    # sub-sample estimates scatter around the full-sample estimate with about 10x its variance
+    z = (est.mean_bs_mean[1:] - full_mean[1:]) / np.sqrt(10 * full_var[1:] / 20 + 1e-30)
+    assert np.all(np.abs(z) < 6), z
+    assert np.allclose(est.mean_bs_var[1:], 10 * full_var[1:], rtol=0.8)
+    # sub-sample sizes: hypergeometric per chunk with parameters reset for every chunk (as in the reference,
+    # quantity.py:343-353), so the totals only match the request on average (test_quantity_concept.py:646)
+    sub = q.subsample(sample_vec=sample_vec)
+    from mlmc_amd.quantity import quantity_estimate as qe
+    sizes = np.mean([qe.estimate_mean(qe.moments(sub, fn)).n_samples for _ in range(20)], axis=0)
+    assert np.allclose(sizes, sample_vec, rtol=0.25)
+
+
+def test_estimate_domain(hip):
+    from mlmc_amd.estimator import Estimate, estimate_domain
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    steps = [0.5, 0.07]
+    levels = level_arrays([5000, 5000], steps, 1, 9)
+    st = _storage(levels, steps, _scalar_spec())
+    q = make_root_quantity(st, _scalar_spec())['q'][1]['0'][0, 0]
+    lo, hi = Estimate.estimate_domain(q, st, quantile=0.01)
+    fine0 = levels[0][0][0]
+    fine0 = fine0[~np.isnan(fine0)]
+    ref = np.percentile(fine0, [1, 99])          # the reference looks at the level-0 chunk for every level (estimator.py:294)
+    assert lo == ref[0] and hi == ref[1]
+    lo2, hi2 = Estimate.estimate_domain(q, st)
+    assert lo2 == lo and hi2 == hi

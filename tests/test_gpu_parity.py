@@ -405,3 +405,55 @@ def test_rccl_allreduce_path_single_rank(hip):
                          capture_output=True, text=True, timeout=600)
     d0 = json.loads([l for l in ref.stdout.splitlines() if l.startswith("{")][-1])
     assert d0["result_check"] == d["result_check"]
+
+
+def test_covariance_full_size_properties(hip):
+    """BASELINE configs[2] scale (5 levels x 1e7 samples, R = 64) from HBM-resident tensors: size-independent properties
+    of the covariance estimate + C-oracle parity on a prefix."""
+    import torch
+    from mlmc_amd import Legendre
+    from mlmc_amd.engine import LevelAccumulator, level_stats
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    L, n_l, R = 5, 10_000_000, 64
+    steps = [s[0] for s in onp.determine_level_parameters(L, [0.5, 0.01])]
+    fn = Legendre(R, dom)
+    dev = []
+    gen = torch.Generator(device="cuda")
+    for l in range(L):
+        gen.manual_seed(77 + l)
+        x = torch.randn(n_l, dtype=torch.float64, device="cuda", generator=gen)
+        root = torch.sqrt(1e-4 + x.abs())
+        dev.append(((x + steps[l] * root).contiguous(), None if l == 0 else (x + steps[l - 1] * root).contiguous()))
+    acc = LevelAccumulator(fn, L, LevelAccumulator.COV)
+    accm = LevelAccumulator(fn, L)
+    for l in range(L):
+        acc.push(l, *dev[l])
+        accm.push(l, *dev[l])
+    n, n_rm, s, sp = acc.finalize()
+    nm, n_rm_m, sm, spm = accm.finalize()
+    assert np.array_equal(n, nm) and np.array_equal(n_rm, n_rm_m) and np.all(n + n_rm == n_l)
+    S = s.reshape(L, R, R)
+    SP = sp.reshape(L, R, R)
+    assert np.array_equal(S, S.transpose(0, 2, 1)) and np.array_equal(SP, SP.transpose(0, 2, 1))      # exactly symmetric
+    assert S[0, 0, 0] == float(n[0]) and not S[1:, 0, 0].any()                                       # P0 P0: counts / exact zeros
+    # first row/column of the covariance sums = the moment sums; squares likewise (P0 = 1)
+    rms = np.sqrt(spm / n[:, None]) * n[:, None]
+    assert close(S[:, 0, :], sm, rms, 1e-10) and close(SP[:, 0, :], spm, None, 1e-10)
+    assert np.all(SP >= 0)
+    # Cauchy-Schwarz on the level-0 second moments: (sum f_i f_j)^2 <= (sum f_i^2)(sum f_j^2)
+    d0 = np.diag(S[0])
+    assert np.all(S[0] ** 2 <= np.outer(d0, d0) * (1 + 1e-12))
+    # C oracle on a short prefix (the reference form costs O(R^2) per sample)
+    k = 20000
+    accp = LevelAccumulator(fn, L, LevelAccumulator.COV)
+    for l in range(L):
+        f, c = dev[l]
+        accp.push(l, f[:k], None if c is None else c[:k])
+    n3, n_rm3, s3, sp3 = accp.finalize()
+    b = onp.Basis(onp.LEGENDRE, R, dom)
+    for l in (0, 2, 4):
+        f, c = dev[l]
+        nk, nr, so, spo = oracle_c.cov_level(b, f[:k].cpu().numpy(), None if c is None else c[:k].cpu().numpy())
+        assert nk == n3[l] and nr == n_rm3[l]
+        rms_l = np.sqrt(spo / nk) * nk
+        assert close(s3[l], so, rms_l, 1e-10) and close(sp3[l], spo, None, 1e-10)
