@@ -140,6 +140,12 @@ int mlmc_density_eval(const mlmc_basis *b, const double *lambda, const double *s
 int mlmc_density_integrate(const mlmc_basis *b, const double *lambda, const double *sigma, int32_t R1, const double *lo,
                            const double *hi, int64_t n, int32_t degree, double *out);
 
+/* ---- sample percentiles (Estimate.estimate_domain, mlmc/estimator.py:275-302) -------------------------- */
+/* out[i] = np.percentile(x[~isnan(x)], q_percent[i]) (NumPy "linear" method), bit-identical: exact order statistics by
+ * a radix select on the device + NumPy's interpolation formula.  n_valid (may be NULL) = number of non-NaN values. */
+int mlmc_percentiles(const double *x, int64_t n, const double *q_percent, int32_t nq, double *out, int64_t *n_valid,
+                     int mem_kind);
+
 #ifdef __cplusplus
 }
 #endif

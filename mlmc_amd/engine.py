@@ -173,3 +173,20 @@ def level_stats(n, s, sp):
             else:
                 l_vars.append(np.full(len(sl), np.inf))
     return np.array(l_means), np.array(l_vars)
+
+
+def percentiles(values, q_percent):
+    """np.percentile(values[~isnan(values)], q_percent) evaluated on the device (radix select), bit-identical to NumPy's
+    "linear" method.  values: NumPy array or torch CUDA tensor (flattened)."""
+    q = _lib.as_f64(np.atleast_1d(q_percent))
+    out = np.empty(q.size, dtype=np.float64)
+    if isinstance(values, np.ndarray):
+        values = _lib.as_f64(values.reshape(-1))
+        n = values.size
+    else:
+        values = values.reshape(-1).contiguous()
+        n = values.numel()
+    n_valid = C.c_int64()
+    _lib.check(_lib.lib().mlmc_percentiles(_lib.ptr(values), int(n), _lib.ptr(q), int(q.size), _lib.ptr(out), C.byref(n_valid),
+                                           _lib.mem_kind(values)))
+    return out

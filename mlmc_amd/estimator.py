@@ -6,6 +6,7 @@ Every pass over the samples (moments, covariance, level variances) goes through
 """
 import numpy as np
 
+from . import engine
 from .quantity import quantity_estimate as qe
 from .quantity.quantity_spec import ChunkSpec
 from .quantity.quantity_types import ScalarType
@@ -152,8 +153,8 @@ class Estimate:
         for level_id in range(sample_storage.get_n_levels()):
             chunk_spec = next(sample_storage.chunks(n_samples=sample_storage.get_n_collected()[level_id]))
             fine = np.squeeze(quantity.samples(chunk_spec)[..., 0])
-            fine = fine[~np.isnan(fine)]
-            ranges.append(np.percentile(fine, [100 * quantile, 100 * (1 - quantile)]))
+            # NaN removal + np.percentile of the reference (:298-299) as one device call (exact radix select)
+            ranges.append(engine.percentiles(fine, [100 * quantile, 100 * (1 - quantile)]))
         ranges = np.array(ranges)
         return np.min(ranges[:, 0]), np.max(ranges[:, 1])
 
@@ -187,7 +188,10 @@ def estimate_domain(quantity, sample_storage, quantile=None):
         n0 = sample_storage.get_n_collected()[0]
         chunk_spec = next(sample_storage.chunks(level_id=level_id, n_samples=n0))
         fine = np.squeeze(quantity.samples(chunk_spec)[..., 0])
-        ranges.append(np.percentile(fine, [100 * quantile, 100 * (1 - quantile)]))
+        if np.isnan(fine).any():
+            ranges.append(np.array([np.nan, np.nan]))       # the module-level variant does not drop NaNs (reference :360)
+        else:
+            ranges.append(engine.percentiles(fine, [100 * quantile, 100 * (1 - quantile)]))
     ranges = np.array(ranges)
     return np.min(ranges[:, 0]), np.max(ranges[:, 1])
 

@@ -457,3 +457,22 @@ def test_covariance_full_size_properties(hip):
         assert nk == n3[l] and nr == n_rm3[l]
         rms_l = np.sqrt(spo / nk) * nk
         assert close(s3[l], so, rms_l, 1e-10) and close(sp3[l], spo, None, 1e-10)
+
+
+def test_percentiles_bit_identical_to_numpy(hip):
+    """mlmc_percentiles (device radix select) == np.percentile on the NaN-free values, bit for bit."""
+    import torch
+    from mlmc_amd.engine import percentiles
+    rng = np.random.default_rng(11)
+    cases = [rng.normal(size=100003), rng.normal(size=7) * 1e-300, np.array([3.0]), np.array([2.0, -1.0]),
+             np.concatenate([rng.normal(size=5000), [np.nan] * 17, [np.inf, -np.inf, 0.0, -0.0]]),
+             np.round(rng.normal(size=20000), 1),                      # many ties
+             -np.abs(rng.lognormal(size=30011)) * 1e5]
+    qs = [0.0, 1.0, 0.01, 25.0, 50.0, 99.0, 99.999, 100.0]
+    for x in cases:
+        ref = np.percentile(x[~np.isnan(x)], qs)
+        got = percentiles(x, qs)
+        assert np.array_equal(got, ref, equal_nan=True), (x.size, got, ref)    # +-inf neighbours interpolate to NaN in NumPy too
+    x = rng.normal(size=3_000_001)
+    xt = torch.from_numpy(x).cuda()
+    assert np.array_equal(percentiles(xt, [1.0, 99.0]), np.percentile(x, [1.0, 99.0]))
