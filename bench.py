@@ -51,8 +51,8 @@ def synth_device(level, n, steps, seed, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -128,8 +128,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
     for _ in range(args.warmup):
         one_estimate()
+    # no cyclic-GC pauses inside the timed region (a gen-2 collection of the torch-sized heap costs ~40 ms)
+    gc.collect()
+    gc.disable()
     # kernel-time bookkeeping of the timed region only
     kt = [0.0, 0, 0]
     sync()
@@ -142,6 +146,7 @@ def main():
         kt[2] += nbytes
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
