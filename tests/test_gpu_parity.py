@@ -476,3 +476,49 @@ def test_percentiles_bit_identical_to_numpy(hip):
     x = rng.normal(size=3_000_001)
     xt = torch.from_numpy(x).cuda()
     assert np.array_equal(percentiles(xt, [1.0, 99.0]), np.percentile(x, [1.0, 99.0]))
+
+
+def _sharded_worker(rank, world, port, N, steps, R, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mlmc_amd import _lib, Legendre
+        from mlmc_amd.engine import LevelAccumulator, shard_bounds
+        _lib.init(0)                                   # both ranks share the one GPU of the test box
+        dom = (-3.7190164854556804, 3.7190164854556804)
+        levels = level_arrays(N, steps, 1, 13)
+        for mode, tag in ((LevelAccumulator.MOMENTS, "mom"), (LevelAccumulator.COV, "cov")):
+            acc = LevelAccumulator(Legendre(R, dom), len(N), mode)
+            for l, (f, c) in enumerate(levels):
+                lo, hi = shard_bounds(f.shape[1], rank, world)
+                acc.push(l, f[0, lo:hi], None if c is None else c[0, lo:hi])
+            n, n_rm, s, sp = acc.finalize()            # all-reduce over the two ranks inside
+            np.savez(os.path.join(out_dir, f"{tag}_rank{rank}.npz"), n=n, n_rm=n_rm, s=s, sp=sp)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_estimate_on_gpu(hip, tmp_path):
+    """The N > 1 path with real kernels: two processes (gloo transport, both on the single GPU of the box) push disjoint
+    shards of every level; after the packed all-reduce every rank holds the same sums as one process over all samples."""
+    import socket
+    import torch.multiprocessing as mp
+    from mlmc_amd import Legendre
+    from mlmc_amd.engine import LevelAccumulator
+    N, steps, R = [50001, 30000, 17777], [0.5, 0.07, 0.01], 12
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_sharded_worker, args=(2, port, N, steps, R, str(tmp_path)), nprocs=2, join=True)
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    levels = level_arrays(N, steps, 1, 13)
+    for mode, tag in ((LevelAccumulator.MOMENTS, "mom"), (LevelAccumulator.COV, "cov")):
+        n, n_rm, s, sp = _run_accum(Legendre(R, dom), levels, mode=mode)
+        r0, r1 = np.load(tmp_path / f"{tag}_rank0.npz"), np.load(tmp_path / f"{tag}_rank1.npz")
+        for k in ("n", "n_rm", "s", "sp"):
+            assert np.array_equal(r0[k], r1[k])
+        assert np.array_equal(r0["n"], n) and np.array_equal(r0["n_rm"], n_rm)          # counts reduce exactly
+        scale = np.sqrt(np.abs(sp) * np.maximum(n[:, None], 1))
+        assert close(r0["s"], s, scale, 1e-12) and close(r0["sp"], sp, None, 1e-12)
