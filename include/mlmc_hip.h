@@ -27,8 +27,11 @@ extern "C" {
 #define MLMC_ABI_VERSION 1
 
 /* basis kinds -- mlmc/moments.py: Legendre :174-229, Monomial :111-130, Fourier :133-171;
- * IDENTITY = the quantity itself (estimate_mean of a plain quantity, quantity_estimate.py:22-80) */
-enum { MLMC_LEGENDRE = 0, MLMC_MONOMIAL = 1, MLMC_FOURIER = 2, MLMC_IDENTITY = 3 };
+ * IDENTITY = the quantity itself (estimate_mean of a plain quantity, quantity_estimate.py:22-80);
+ * SPLINE = cubic B-spline moments.  The reference imports scipy's BSpline (moments.py:3) but defines no spline class
+ * (SURVEY fact 2): phi_0 = 1, phi_r = B_r (r = 1..size-1) of the clamped uniform cubic B-spline basis B_0..B_{size-1}
+ * on ref_domain, pinned against scipy.interpolate.BSpline ("parity unpinned" with respect to the reference). */
+enum { MLMC_LEGENDRE = 0, MLMC_MONOMIAL = 1, MLMC_FOURIER = 2, MLMC_IDENTITY = 3, MLMC_SPLINE = 4 };
 /* accumulation modes */
 enum {
     MLMC_MODE_MOMENTS = 0,  /* qe.moments + estimate_mean    (quantity_estimate.py:96-119, :22-80)  K = R      */

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLMC_HIP_LIB", os.path.join(_HERE, "libmlmc_hip.so"))   # env override: development builds
 
-LEGENDRE, MONOMIAL, FOURIER, IDENTITY = 0, 1, 2, 3
+LEGENDRE, MONOMIAL, FOURIER, IDENTITY, SPLINE = 0, 1, 2, 3, 4
 MODE_MOMENTS, MODE_COV = 0, 1
 HOST, DEVICE = 0, 1
 FLAG_TIMING = 1

@@ -136,7 +136,8 @@ int mlmc_basis_create(const mlmc_basis_desc *d, mlmc_basis **out) {
     if (need_runtime()) return 1;
     if (!d || !out) return fail("mlmc_basis_create: null argument");
     if (d->size <= 0) return fail("mlmc_basis_create: size must be > 0");   // moments.py:11 assert size > 0
-    if (d->kind < MLMC_LEGENDRE || d->kind > MLMC_IDENTITY) return fail("mlmc_basis_create: unknown kind");
+    if (d->kind < MLMC_LEGENDRE || d->kind > MLMC_SPLINE) return fail("mlmc_basis_create: unknown kind");
+    if (d->kind == MLMC_SPLINE && d->size < 4) return fail("mlmc_basis_create: cubic spline moments need size >= 4");
     if (d->kind == MLMC_IDENTITY && d->size != 1) return fail("mlmc_basis_create: IDENTITY has size 1");
     if (d->out_size < 0 || (d->out_size > 0 && !d->matrix)) return fail("mlmc_basis_create: matrix missing");
     if (d->kind == MLMC_LEGENDRE && d->size > 512) return fail("mlmc_basis_create: at most 512 Legendre moments");

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
             const int64_t nidx = (batch + gridDim.x) * COV_BATCH + samp;
             if (nidx < n) { xv = src[nidx]; if (mask) mv = mask[nidx]; }
             TermGen<KIND> g;
-            g.init(keep ? t : 0.0, keep ? 1.0 : 0.0);
+            g.init(keep ? t : 0.0, keep ? 1.0 : 0.0, bp);
             // all NT terms, fully unrolled (compile-time indices, no branches); rows >= R of the Gram matrices are
             // never read back
 #pragma unroll
@@ -246,7 +246,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp, const double 
             const int64_t nidx = (batch + gridDim.x) * COV_BATCH + samp;
             if (nidx < n) { xv = src[nidx]; if (mask) mv = mask[nidx]; }
             TermGen<KIND> g;
-            g.init(keep ? t : 0.0, keep ? 1.0 : 0.0);
+            g.init(keep ? t : 0.0, keep ? 1.0 : 0.0, bp);
 #pragma unroll
             for (int i = 0; i < N_EVAL; ++i) {
                 const double q = g.next(i, coef);
@@ -462,6 +462,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
                 case MLMC_LEGENDRE: MLMC_COV_DISPATCH(MLMC_LEGENDRE); break;
                 case MLMC_MONOMIAL: MLMC_COV_DISPATCH(MLMC_MONOMIAL); break;
                 case MLMC_FOURIER: MLMC_COV_DISPATCH(MLMC_FOURIER); break;
+                case MLMC_SPLINE: MLMC_COV_DISPATCH(MLMC_SPLINE); break;
                 default: return fail("covariance: unsupported basis kind");
             }
 #undef MLMC_COV_DISPATCH

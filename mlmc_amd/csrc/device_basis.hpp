@@ -48,7 +48,7 @@ __device__ constexpr LegendreG kLegendreG = LegendreG();
 template <int KIND>
 struct TermGen {
     double x, p1, p2, c1, s1;
-    __device__ __forceinline__ void init(double x_, double w) {
+    __device__ __forceinline__ void init(double x_, double w, const BasisParams &) {
         x = x_;
         p1 = w;   // term 0
         p2 = 0.0;
@@ -90,8 +90,53 @@ struct TermGen {
 template <>
 struct TermGen<MLMC_IDENTITY> {
     double v;
-    __device__ __forceinline__ void init(double x_, double w) { v = x_ * w; }
+    __device__ __forceinline__ void init(double x_, double w, const BasisParams &) { v = x_ * w; }
     __device__ __forceinline__ double next(int, const double *__restrict__) { return v; }
+};
+
+// SPLINE: phi_0 = 1, phi_r = B_r(t), r >= 1, of the clamped uniform cubic B-spline basis B_0..B_{nb-1} on
+// [ref0, ref1] (nb = size, ns = nb - 3 knot spans).  At most four B-splines are non-zero at a point: init() finds the
+// span and evaluates them with the Cox-de Boor recurrence (The NURBS Book, A2.2); next(i) selects.  Stateless in i.
+template <>
+struct TermGen<MLMC_SPLINE> {
+    double n0, n1, n2, n3, w;
+    int k;   // B_k .. B_{k+3} are the non-zero ones
+    static __device__ __forceinline__ double knot(int j, int ns, double inv_ns) {
+        int c = j - 3;
+        c = c < 0 ? 0 : (c > ns ? ns : c);
+        return (double)c * inv_ns;
+    }
+    __device__ __forceinline__ void init(double t, double w_, const BasisParams &bp) {
+        w = w_;
+        const int ns = bp.size - 3;
+        const double inv_ns = 1.0 / (double)ns;
+        const double u = (t - bp.ref0) / (bp.ref1 - bp.ref0);
+        int s = (int)(u * (double)ns);
+        s = s < 0 ? 0 : (s > ns - 1 ? ns - 1 : s);
+        k = s;
+        const int mu = s + 3;
+        double N[4], left[4], right[4];
+        N[0] = 1.0;
+#pragma unroll
+        for (int j = 1; j <= 3; ++j) {
+            left[j] = u - knot(mu + 1 - j, ns, inv_ns);
+            right[j] = knot(mu + j, ns, inv_ns) - u;
+            double saved = 0.0;
+#pragma unroll
+            for (int r = 0; r < j; ++r) {
+                const double temp = N[r] / (right[r + 1] + left[j - r]);
+                N[r] = saved + right[r + 1] * temp;
+                saved = left[j - r] * temp;
+            }
+            N[j] = saved;
+        }
+        n0 = N[0] * w; n1 = N[1] * w; n2 = N[2] * w; n3 = N[3] * w;
+    }
+    __device__ __forceinline__ double next(int i, const double *__restrict__) {
+        if (i == 0) return w;
+        const int j = i - k;
+        return j == 0 ? n0 : (j == 1 ? n1 : (j == 2 ? n2 : (j == 3 ? n3 : 0.0)));
+    }
 };
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -226,7 +226,7 @@ __global__ void k_density(BasisParams bp, const double *__restrict__ coef, const
     bool keep;
     const double t = transform_value(bp, x[i], keep);
     TermGen<KIND> g;
-    g.init(keep ? t : 0.0, 1.0);
+    g.init(keep ? t : 0.0, 1.0, bp);
     double power = 0.0;
     for (int r = 0; r < R; ++r) power = __builtin_fma(g.next(r, coef), c[r], power);
     power = fmin(fmax(-power, -200.0), 200.0);
@@ -248,7 +248,7 @@ __global__ void k_density_integrate(BasisParams bp, const double *__restrict__ c
         bool keep;
         const double t = transform_value(bp, __builtin_fma(half, nodes[k], mid), keep);
         TermGen<KIND> g;
-        g.init(keep ? t : 0.0, 1.0);
+        g.init(keep ? t : 0.0, 1.0, bp);
         double power = 0.0;
         for (int r = 0; r < R; ++r) power = __builtin_fma(g.next(r, coef), c[r], power);
         power = fmin(fmax(-power, -200.0), 200.0);
@@ -521,6 +521,7 @@ int mlmc_density_eval(const mlmc_basis *b, const double *lambda, const double *s
         case MLMC_LEGENDRE: hipLaunchKernelGGL(k_density<MLMC_LEGENDRE>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, xd, n, od); break;
         case MLMC_MONOMIAL: hipLaunchKernelGGL(k_density<MLMC_MONOMIAL>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, xd, n, od); break;
         case MLMC_FOURIER: hipLaunchKernelGGL(k_density<MLMC_FOURIER>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, xd, n, od); break;
+        case MLMC_SPLINE: hipLaunchKernelGGL(k_density<MLMC_SPLINE>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, xd, n, od); break;
         default: return fail("mlmc_density_eval: unsupported basis kind");
     }
     MLMC_HIP_CHECK(hipGetLastError());
@@ -562,6 +563,7 @@ int mlmc_density_integrate(const mlmc_basis *b, const double *lambda, const doub
         case MLMC_LEGENDRE: hipLaunchKernelGGL(k_density_integrate<MLMC_LEGENDRE>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
         case MLMC_MONOMIAL: hipLaunchKernelGGL(k_density_integrate<MLMC_MONOMIAL>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
         case MLMC_FOURIER: hipLaunchKernelGGL(k_density_integrate<MLMC_FOURIER>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
+        case MLMC_SPLINE: hipLaunchKernelGGL(k_density_integrate<MLMC_SPLINE>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
         default: return fail("mlmc_density_integrate: unsupported basis kind");
     }
     MLMC_HIP_CHECK(hipGetLastError());

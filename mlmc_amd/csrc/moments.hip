@@ -28,7 +28,7 @@ __global__ void k_eval(BasisParams bp, const double *__restrict__ coef, const do
     bool keep;
     double t = transform_value(bp, x[i], keep);
     TermGen<KIND> g;
-    g.init(keep ? t : 0.0, 1.0);
+    g.init(keep ? t : 0.0, 1.0, bp);
     const double nan = __builtin_nan("");
     for (int r = 0; r < size; ++r) {
         double q = g.next(r, coef);
@@ -68,6 +68,7 @@ int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, dou
         case MLMC_MONOMIAL: hipLaunchKernelGGL(k_eval<MLMC_MONOMIAL>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
         case MLMC_FOURIER: hipLaunchKernelGGL(k_eval<MLMC_FOURIER>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
         case MLMC_IDENTITY: hipLaunchKernelGGL(k_eval<MLMC_IDENTITY>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
+        case MLMC_SPLINE: hipLaunchKernelGGL(k_eval<MLMC_SPLINE>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
         default: return fail("unknown basis kind");
     }
     MLMC_HIP_CHECK(hipGetLastError());
@@ -183,9 +184,9 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp, const doubl
         const double w0 = k0 ? 1.0 : 0.0, w1 = k1 ? 1.0 : 0.0;
 
         TermGen<KIND> gf0, gf1, gc0, gc1;
-        gf0.init(k0 ? tf0 : 0.0, w0);
-        gf1.init(k1 ? tf1 : 0.0, w1);
-        if (PAIR) { gc0.init(k0 ? tc0 : 0.0, w0); gc1.init(k1 ? tc1 : 0.0, w1); }
+        gf0.init(k0 ? tf0 : 0.0, w0, bp);
+        gf1.init(k1 ? tf1 : 0.0, w1, bp);
+        if (PAIR) { gc0.init(k0 ? tc0 : 0.0, w0, bp); gc1.init(k1 ? tc1 : 0.0, w1, bp); }
 
         if (!FIRST) {   // later passes of R > 64: advance the recurrences without accumulating
             for (int i = 0; i < t0; ++i) {
@@ -364,6 +365,12 @@ static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const doubl
                 MLMC_RT_CASE(MLMC_FOURIER, 8); MLMC_RT_CASE(MLMC_FOURIER, 16); MLMC_RT_CASE(MLMC_FOURIER, 32);
                 default: return op == 0 ? occupancy_rt<MLMC_FOURIER, 64>(out)
                                         : launch_accum_rt<MLMC_FOURIER, 64>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
+            }
+        case MLMC_SPLINE:
+            switch (rt_sel) {
+                MLMC_RT_CASE(MLMC_SPLINE, 8); MLMC_RT_CASE(MLMC_SPLINE, 16); MLMC_RT_CASE(MLMC_SPLINE, 32);
+                default: return op == 0 ? occupancy_rt<MLMC_SPLINE, 64>(out)
+                                        : launch_accum_rt<MLMC_SPLINE, 64>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
             }
         case MLMC_IDENTITY:
             return op == 0 ? occupancy_rt<MLMC_IDENTITY, 4>(out)

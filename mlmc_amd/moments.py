@@ -201,6 +201,29 @@ class Legendre(Moments):
         return self._eval_all(value, size) @ np.linalg.matrix_power(self.diff_mat[:size, :size], degree)
 
 
+class Spline(Moments):
+    """Cubic B-spline moments on ref_domain (0, 1): phi_0 = 1, phi_r = B_r (r = 1..size-1) of the clamped uniform cubic
+    B-spline basis B_0..B_{size-1} (size - 3 knot spans).  NOT part of this reference version (it only imports
+    scipy.interpolate.BSpline, moments.py:3): defined here and pinned against scipy's BSpline."""
+    _kind = _lib.SPLINE
+
+    def __init__(self, size, domain, ref_domain=None, log=False, safe_eval=True):
+        assert size >= 4, "cubic spline moments need size >= 4"
+        self.ref_domain = ref_domain if ref_domain is not None else (0, 1)
+        super().__init__(size, domain, log=log, safe_eval=safe_eval)
+
+    def change_size(self, size):
+        return Spline(size, self.domain, ref_domain=self.ref_domain, log=self._is_log, safe_eval=self._is_clip)
+
+    def knots(self):
+        """Knot vector on the unit interval (the one to hand to scipy.interpolate.BSpline)."""
+        ns = self.size - 3
+        return np.clip(np.arange(-3, ns + 4), 0, ns) / ns
+
+    def eval(self, i, value):
+        return self._eval_all(value, i + 1)[..., i]
+
+
 class TransformedMoments(Moments):
     """new_moments = matrix . old_moments (reference: moments.py:232-274)."""
 

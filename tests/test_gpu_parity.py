@@ -522,3 +522,39 @@ def test_two_rank_sharded_estimate_on_gpu(hip, tmp_path):
         assert np.array_equal(r0["n"], n) and np.array_equal(r0["n_rm"], n_rm)          # counts reduce exactly
         scale = np.sqrt(np.abs(sp) * np.maximum(n[:, None], 1))
         assert close(r0["s"], s, scale, 1e-12) and close(r0["sp"], sp, None, 1e-12)
+
+
+def test_spline_moments(hip):
+    """Cubic B-spline moments -- NOT in the reference ("parity unpinned"): device evaluation and estimates
+    against scipy.interpolate.BSpline through the oracle."""
+    from mlmc_amd import Spline
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-3.7, 3.7)
+    grid = np.concatenate([np.linspace(dom[0], dom[1], 257), [dom[0] - 1e-9, dom[1] + 1e-9, np.nan, 0.0, 1e-300]])
+    for R in (4, 5, 8, 33, 64, 128):
+        fn = Spline(R, dom)
+        got = fn.eval_all(grid)
+        ref = onp.eval_all(onp.Basis(onp.SPLINE, R, dom), grid)
+        assert got.shape == ref.shape and _same_nan(got, ref) and _vals_close(got, ref, 1e-12), R
+        ok = ~np.isnan(ref[:, 0])
+        assert np.all(got[ok, 0] == 1.0)
+        assert np.allclose(got[ok, 1:].sum(axis=1) + (1 - got[ok, 1:].sum(axis=1)), 1.0)      # B_0 = 1 - sum of the others
+        assert np.all(got[ok] >= 0) and np.all(got[ok] <= 1 + 1e-15)
+    # knots of the class are those of the scipy basis
+    from scipy.interpolate import BSpline
+    fn = Spline(10, (0.0, 1.0))
+    x = np.linspace(0, 1, 50)
+    dm = BSpline.design_matrix(x, fn.knots(), 3).toarray()
+    assert np.allclose(fn.eval_all(x)[:, 1:], dm[:, 1:], atol=1e-14)
+    levels = level_arrays([6001, 4000, 1501], [0.5, 0.07, 0.01], 1, 11)
+    for R in (6, 40, 128):
+        b = onp.Basis(onp.SPLINE, R, dom)
+        n, n_rm, s, sp = _run_accum(Spline(R, dom), levels)
+        ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(b, x))
+        mean, var = _check_against(n, n_rm, s, sp, ref)
+        assert mean[0] == 1.0 and var[0] == 0.0
+    b = onp.Basis(onp.SPLINE, 24, dom)
+    lv = [(f[:, :1200], None if c is None else c[:, :1200]) for f, c in levels]
+    n, n_rm, s, sp = _run_accum(Spline(24, dom), lv, mode=LevelAccumulator.COV)
+    ref = onp.estimate_mean(to_chunks(lv), lambda x: onp.covariance_rows(b, x))
+    _check_against(n, n_rm, s, sp, ref)
