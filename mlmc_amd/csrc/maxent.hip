@@ -48,19 +48,29 @@ __global__ void k_me_density(const double *__restrict__ Phi, const double *__res
     if (threadIdx.x == 0) block_sums[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-// g_i = mu_i/s_i - sum_q Phi[q][i] rho_q w_q ; also scal[0] = F = mu~.l + sum rho w, scal[1] = int rho phi_0 s_0
-__global__ void k_me_grad(const double *__restrict__ Phi, const double *__restrict__ rhow, const double *__restrict__ mu_s,
-                          const double *__restrict__ lam, const double *__restrict__ sigma, int Q, int R1,
-                          const double *__restrict__ block_sums, int n_blocks, double *__restrict__ g,
-                          double *__restrict__ scal) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < R1) {
+// g_i = mu_i/s_i - sum_q Phi[q][i] rho_q w_q : one 256-thread block per moment i (fixed-order block reduction).
+// Block 0 also sets scal[0] = F = mu~.l + sum rho w, scal[1] = int rho phi_0 s_0, scal[2] = sum rho w.
+// grad == 0: functional only (line search) -- a single block.
+__global__ __launch_bounds__(256) void k_me_grad(const double *__restrict__ Phi, const double *__restrict__ rhow,
+                                                 const double *__restrict__ mu_s, const double *__restrict__ lam,
+                                                 const double *__restrict__ sigma, int Q, int R1,
+                                                 const double *__restrict__ block_sums, int n_blocks, int grad,
+                                                 double *__restrict__ g, double *__restrict__ scal) {
+    __shared__ double red[4];
+    const int i = blockIdx.x;
+    if (grad) {
         double acc = 0.0;
-        for (int q = 0; q < Q; ++q) acc = __builtin_fma(Phi[(int64_t)q * R1 + i], rhow[q], acc);
-        g[i] = mu_s[i] - acc;
-        if (i == 0) scal[1] = acc * sigma[0];
+        for (int q = threadIdx.x; q < Q; q += 256) acc = __builtin_fma(Phi[(int64_t)q * R1 + i], rhow[q], acc);
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+            g[i] = mu_s[i] - tot;
+            if (i == 0) scal[1] = tot * sigma[0];
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 64) {
         double integral = 0.0;
         for (int b = 0; b < n_blocks; ++b) integral += block_sums[b];
         double lin = 0.0;
@@ -399,15 +409,15 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
     }
 
     double scal[8];
-    auto eval_F = [&](const double *d_l) -> int {   // scal[0] = F (penalties excluded) at d_l
+    auto eval_F = [&](const double *d_l, int grad) -> int {   // scal[0] = F (penalties excluded) at d_l; gradient if asked
         hipLaunchKernelGGL(k_me_density, dim3(n_dblocks), dim3(256), 0, st, d_Phi.d(), d_w.d(), d_l, Q, R1, d_rhow.d(), d_bs.d());
-        hipLaunchKernelGGL(k_me_grad, dim3((R1 + 127) / 128), dim3(128), 0, st, d_Phi.d(), d_rhow.d(), d_mus.d(), d_l, d_sig.d(), Q, R1,
-                           d_bs.d(), n_dblocks, d_g.d(), d_scal.d());
+        hipLaunchKernelGGL(k_me_grad, dim3(grad ? R1 : 1), dim3(256), 0, st, d_Phi.d(), d_rhow.d(), d_mus.d(), d_l, d_sig.d(), Q, R1,
+                           d_bs.d(), n_dblocks, grad, d_g.d(), d_scal.d());
         MLMC_HIP_CHECK(hipGetLastError());
         return 0;
     };
     auto eval_full = [&](const double *d_l, double tau) -> int {
-        if (int rc = eval_F(d_l)) return rc;
+        if (int rc = eval_F(d_l, 1)) return rc;
         hipLaunchKernelGGL(k_me_hessian, dim3(T * (T + 1) / 2), dim3(256), 0, st, d_Phi.d(), d_rhow.d(), Q, R1, T, d_H.d());
         if (use_pen)
             hipLaunchKernelGGL(k_me_penalty, dim3(1), dim3(256), 0, st, d_end.d(), d_l, d_prev.d(), n_prev, opts->stab_penalty,
@@ -449,7 +459,7 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
             hipLaunchKernelGGL(k_me_axpy, dim3((R1 + 127) / 128), dim3(128), 0, st, d_lam.d(), d_dir.d(), alpha, R1, d_trial.d());
             double Ft, gt;
             if (!use_pen) {
-                if (int rc = eval_F(d_trial.d())) return rc;
+                if (int rc = eval_F(d_trial.d(), 0)) return rc;
                 double s2[8];
                 MLMC_HIP_CHECK(hipMemcpyAsync(s2, d_scal.p, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
                 MLMC_HIP_CHECK(hipStreamSynchronize(st));
