@@ -32,6 +32,9 @@ CONFIGS = {
             workload="BASELINE configs[1]: 3 levels x 1e7 synthetic samples per GPU, Legendre n_moments=32, mean+var estimate"),
     3: dict(L=5, n_per_level=10_000_000, R=64, mode="cov",
             workload="BASELINE configs[2]: 5 levels x 1e7 synthetic samples per GPU, Legendre n_moments=64, moment covariance mean+var + level-variance regression + n_samples re-allocation"),
+    5: dict(L=1, n_per_level=12_500_000, R=128, mode="moments", basis="Spline",
+            workload="BASELINE configs[4] per-GPU share: 1 level x 1.25e7 synthetic samples per GPU (1e8 over 8 GPUs), Spline "
+                     "n_moments=128 (cubic B-spline moments, not part of the reference), mean+var estimate + max-entropy PDF"),
 }
 
 
@@ -79,7 +82,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
 
-    from mlmc_amd import _lib, Legendre
+    from mlmc_amd import _lib, Legendre, Spline
     from mlmc_amd.engine import LevelAccumulator, level_stats
     from oracle import oracle_np as onp   # checker + cpu_baseline leg only
 
@@ -88,8 +91,8 @@ def main():
     cfg = CONFIGS[args.config]
     L, n_l, R = cfg["L"], cfg["n_per_level"], cfg["R"]
     dom = (-3.7190164854556804, 3.7190164854556804)   # scipy.stats.norm().ppf([1e-4, 1 - 1e-4]) (test/test_run.py:71)
-    steps = [s[0] for s in onp.determine_level_parameters(L, [0.5, 0.01])]
-    fn = Legendre(R, dom)
+    steps = [s[0] for s in onp.determine_level_parameters(L, [0.5, 0.01])] if L > 1 else [0.01]
+    fn = Spline(R, dom) if cfg.get("basis") == "Spline" else Legendre(R, dom)
     mode = LevelAccumulator.MOMENTS if cfg["mode"] == "moments" else LevelAccumulator.COV
     acc = LevelAccumulator(fn, L, mode)
 
@@ -193,7 +196,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["workload"], "levels": L, "samples_per_level_per_gpu": n_l, "n_moments": R,
-                   "basis": "Legendre", "estimate": cfg["mode"], "exchange": "all-reduce of [L,(2+2K)] partial sums" if world > 1 else "none"},
+                   "basis": cfg.get("basis", "Legendre"), "estimate": cfg["mode"], "exchange": "all-reduce of [L,(2+2K)] partial sums" if world > 1 else "none"},
         "roofline": roofline,
         "result_check": {"mean0": float(np.ravel(mean)[0]), "var0": float(np.ravel(var)[0]), "n_removed": [int(v) for v in n_rm]},
     }
@@ -284,7 +287,9 @@ def cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_st
     else:
         n_s, chunk = 6_000, 1_000       # the reference form materialises [2, n, R, R] per chunk
         rows = onp.covariance_rows
-    b = onp.Basis(onp.LEGENDRE, R, dom)
+    b = onp.Basis(onp.SPLINE if cfg.get("basis") == "Spline" else onp.LEGENDRE, R, dom)
+    if cfg.get("basis") == "Spline":
+        n_s, chunk = 400_000, 50_000
     host = [onp.synth_level_samples(l, n_s, steps, seed=4321) for l in range(L)]
     level_chunks = []
     for l, (f, c) in enumerate(host):
@@ -299,7 +304,7 @@ def cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_st
     cpu = {"value": L * n_s * R / cpu_s, "unit": "moment-evals/s", "cores": 1, "kind": "port",
            "sample": "{} levels x {} samples, Legendre R={}, {} estimate, NumPy restatement of the reference path "
                      "(oracle/oracle_np.py), chunks of {}; {:.2f} s on 1 of {} host cores".format(
-                         L, n_s, R, cfg["mode"], chunk, cpu_s, os.cpu_count())}
+                         L, n_s, R, cfg["mode"], chunk, cpu_s, os.cpu_count()).replace("Legendre", cfg.get("basis", "Legendre"))}
     mode = LevelAccumulator.MOMENTS if cfg["mode"] == "moments" else LevelAccumulator.COV
     acc = LevelAccumulator(fn, L, mode)
     for l, (f, c) in enumerate(host):

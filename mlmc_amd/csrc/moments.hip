@@ -306,6 +306,95 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sparse accumulation for SPLINE moments: at most four B-splines are non-zero per value, so a sample touches at most
+// eight of the R sums.  Every wave keeps its own copy of the 2 R sums in LDS and updates it with ds_add_f64 (one wave's
+// atomics hit only its own copy; the four copies are added in a fixed order at the end).  Same segment table, partial
+// rows [block][2 R] and grid reduction as the dense kernel.  phi_0 = 1 is handled through the sample count.
+// ------------------------------------------------------------------------------------------
+constexpr int SPLINE_MAX_R = 512;
+
+__global__ __launch_bounds__(ACC_THREADS) void k_spline_accum(BasisParams bp, SegTable tab, int R, double *__restrict__ partials,
+                                                             int64_t *__restrict__ pcounts) {
+    extern __shared__ double sacc[];              // [4 waves][2][RP], RP = R + 8 (slack for the local 8-window)
+    __shared__ int ldc[4][2];
+    const int RP = R + 8;
+    Seg sg = tab.seg[0];
+#pragma unroll
+    for (int k = 1; k < MAX_SEG; ++k)
+        if (k < tab.nseg && (int)blockIdx.x >= tab.seg[k].block0) sg = tab.seg[k];
+    const int bid = (int)blockIdx.x - sg.block0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * 2 * RP; i += ACC_THREADS) sacc[i] = 0.0;
+    __syncthreads();
+    double *__restrict__ ws = sacc + (size_t)wave * 2 * RP;   // sums of d
+    double *__restrict__ wsp = ws + RP;                        // sums of d^2
+    const bool pair = sg.coarse != nullptr;
+    int n_keep = 0, n_rm = 0;
+    const int64_t T = (int64_t)sg.nblocks * ACC_THREADS;
+    for (int64_t i = (int64_t)bid * ACC_THREADS + threadIdx.x; i < sg.n; i += T) {
+        bool kf, kc = true;
+        const double tf = transform_value(bp, sg.fine[i], kf);
+        double tc = 0.0;
+        if (pair) tc = transform_value(bp, sg.coarse[i], kc);
+        const bool keep = kf && kc && (!sg.mask || sg.mask[i] != 0);
+        n_keep += (int)keep;
+        n_rm += (int)!keep;
+        if (!keep) continue;
+        TermGen<MLMC_SPLINE> gf, gc;
+        gf.init(tf, 1.0, bp);
+        const double nf[4] = {gf.n0, gf.n1, gf.n2, gf.n3};
+        if (!pair) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = gf.k + j;
+                if (r > 0) { atomicAdd(&ws[r], nf[j]); atomicAdd(&wsp[r], nf[j] * nf[j]); }
+            }
+            continue;
+        }
+        gc.init(tc, 1.0, bp);
+        const double nc[4] = {gc.n0, gc.n1, gc.n2, gc.n3};
+        const int delta = gc.k - gf.k;
+        if (delta == 0) {                                     // the common case: fine and coarse in the same knot span
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = gf.k + j;
+                const double d = nf[j] - nc[j];
+                if (r > 0) { atomicAdd(&ws[r], d); atomicAdd(&wsp[r], d * d); }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                     // indices touched by the fine value
+                const int r = gf.k + j, jc = j - delta;       // coarse slot holding the same B-spline, if any
+                const double c = jc == 0 ? nc[0] : (jc == 1 ? nc[1] : (jc == 2 ? nc[2] : (jc == 3 ? nc[3] : 0.0)));
+                const double d = nf[j] - c;
+                if (r > 0) { atomicAdd(&ws[r], d); atomicAdd(&wsp[r], d * d); }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                     // indices touched by the coarse value only
+                const int r = gc.k + j, jf = j + delta;
+                if ((jf < 0 || jf > 3) && r > 0) { atomicAdd(&ws[r], -nc[j]); atomicAdd(&wsp[r], nc[j] * nc[j]); }
+            }
+        }
+    }
+    n_keep = wave_sum_i(n_keep);
+    n_rm = wave_sum_i(n_rm);
+    if (lane == 0) { ldc[wave][0] = n_keep; ldc[wave][1] = n_rm; }
+    __syncthreads();
+    const int keep_block = ldc[0][0] + ldc[1][0] + ldc[2][0] + ldc[3][0];
+    for (int j = threadIdx.x; j < 2 * R; j += ACC_THREADS) {
+        const int which = j / R, r = j % R;
+        const int o = which * RP + r;
+        double v = ((sacc[o] + sacc[2 * RP + o]) + sacc[4 * RP + o]) + sacc[6 * RP + o];
+        if (r == 0) v = pair ? 0.0 : (double)keep_block;     // phi_0 = 1: differences vanish; level 0 counts the samples
+        partials[(int64_t)blockIdx.x * (2 * R) + j] = v;
+    }
+    if (threadIdx.x < 2) {
+        int v = ldc[0][threadIdx.x] + ldc[1][threadIdx.x] + ldc[2][threadIdx.x] + ldc[3][threadIdx.x];
+        pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = v;
+    }
+}
+
 template <int KIND, int RT>
 static int launch_accum_rt(const BasisParams &bp, const double *coef, const SegTable &tab, int total_blocks, int t0,
                            double *partials, int64_t *pcounts) {
@@ -366,12 +455,6 @@ static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const doubl
                 default: return op == 0 ? occupancy_rt<MLMC_FOURIER, 64>(out)
                                         : launch_accum_rt<MLMC_FOURIER, 64>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
             }
-        case MLMC_SPLINE:
-            switch (rt_sel) {
-                MLMC_RT_CASE(MLMC_SPLINE, 8); MLMC_RT_CASE(MLMC_SPLINE, 16); MLMC_RT_CASE(MLMC_SPLINE, 32);
-                default: return op == 0 ? occupancy_rt<MLMC_SPLINE, 64>(out)
-                                        : launch_accum_rt<MLMC_SPLINE, 64>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
-            }
         case MLMC_IDENTITY:
             return op == 0 ? occupancy_rt<MLMC_IDENTITY, 4>(out)
                            : launch_accum_rt<MLMC_IDENTITY, 4>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
@@ -387,12 +470,15 @@ int flush_moments(mlmc_accum *a) {
     hipStream_t st = rt().stream;
     const int R = a->R;
     const BasisParams &bp = a->basis->p;
-    for (int t0 = 0; t0 < R; t0 += MAX_TERMS_PER_PASS) {
+    const bool sparse_spline = bp.kind == MLMC_SPLINE;
+    if (sparse_spline && R > SPLINE_MAX_R) return fail("spline moments: at most 512 basis functions");
+    for (int t0 = 0; t0 < (sparse_spline ? 1 : R); t0 += MAX_TERMS_PER_PASS) {
         const int n_terms = (R - t0 < MAX_TERMS_PER_PASS) ? R - t0 : MAX_TERMS_PER_PASS;
-        const int rt_sel = pick_rt(bp.kind, n_terms);
+        const int rt_sel = sparse_spline ? R : pick_rt(bp.kind, n_terms);
         const int width = 2 * rt_sel;
-        int per_cu = 1;
-        if (int rc = accum_dispatch(0, bp, rt_sel, nullptr, nullptr, 0, 0, nullptr, nullptr, &per_cu)) return rc;
+        int per_cu = 4;
+        if (!sparse_spline)
+            if (int rc = accum_dispatch(0, bp, rt_sel, nullptr, nullptr, 0, 0, nullptr, nullptr, &per_cu)) return rc;
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 4) per_cu = 4;
         const int resident = rt().n_cu * per_cu;
@@ -429,7 +515,13 @@ int flush_moments(mlmc_accum *a) {
         if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)total * width)) return rc;
         if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)total * 2)) return rc;
         if (int rc = timing_begin(a)) return rc;
-        if (int rc = accum_dispatch(1, bp, rt_sel, a->basis->d_coef, &tab, total, t0, a->d_partials, a->d_pcounts, nullptr)) return rc;
+        if (sparse_spline) {
+            const size_t lds = sizeof(double) * 4 * 2 * (size_t)(R + 8);
+            hipLaunchKernelGGL(k_spline_accum, dim3(total), dim3(ACC_THREADS), lds, st, bp, tab, R, a->d_partials, a->d_pcounts);
+            MLMC_HIP_CHECK(hipGetLastError());
+        } else if (int rc = accum_dispatch(1, bp, rt_sel, a->basis->d_coef, &tab, total, t0, a->d_partials, a->d_pcounts, nullptr)) {
+            return rc;
+        }
         if (int rc = timing_end(a)) return rc;
         a->launches += 1;
         a->alg_bytes += bytes;
