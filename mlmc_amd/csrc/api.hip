@@ -219,8 +219,8 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     if (!b || !out) return fail("mlmc_accum_create: null argument");
     if (n_levels <= 0 || n_comp <= 0) return fail("mlmc_accum_create: n_levels and n_comp must be > 0");
     if (mode != MLMC_MODE_MOMENTS && mode != MLMC_MODE_COV) return fail("mlmc_accum_create: unknown mode");
-    if (mode == MLMC_MODE_COV && b->out_size > 0)
-        return fail("mlmc_accum_create: covariance of TransformedMoments is not supported on the device path yet");
+    if (mode == MLMC_MODE_COV && b->out_size > 64)
+        return fail("mlmc_accum_create: covariance of TransformedMoments supports at most 64 moments on the device path");
     mlmc_accum *a = new (std::nothrow) mlmc_accum();
     if (!a) return fail("out of memory");
     a->basis = b;
@@ -229,7 +229,7 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->n_comp = n_comp;
     a->R = b->p.size;
     a->Rout = b->out_size > 0 ? b->out_size : b->p.size;
-    a->RP = ((a->R + 15) / 16) * 16;
+    a->RP = (((mode == MLMC_MODE_COV && b->out_size > 0 ? a->Rout : a->R) + 15) / 16) * 16;
     if (mode == MLMC_MODE_MOMENTS) {
         a->K = (int64_t)n_comp * a->Rout;
         a->int_width = 2 * (int64_t)a->R + (b->out_size > 0 ? (int64_t)a->RP * a->RP : 0);
@@ -272,7 +272,7 @@ int mlmc_accum_reset(mlmc_accum *a) {
 void mlmc_accum_destroy(mlmc_accum *a) {
     if (!a) return;
     if (rt().ready) (void)hipStreamSynchronize(rt().stream);
-    void *ptrs[] = {a->d_state, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c, a->d_mask, a->d_out};
+    void *ptrs[] = {a->d_state, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c, a->d_mask, a->d_out, a->d_vals_f, a->d_vals_c};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (a->h_out) (void)hipHostFree(a->h_out);
@@ -333,6 +333,30 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             const bool defer = mem_kind == MLMC_DEVICE && a->n_comp == 1;
             rc = launch_moments_accum(a, level, m, f_m, c_m, d_mask, n, count, defer);
             if (!rc && a->basis->out_size > 0) rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, false, true);
+        } else if (a->basis->out_size > 0) {
+            // covariance of TransformedMoments: materialise the transformed moment values chunk by chunk
+            // (eval + matrix product), then the MFMA covariance kernel reads them back
+            const int R1 = a->Rout;
+            const int64_t chunk = 1 << 18;
+            const size_t need = sizeof(double) * (size_t)(n < chunk ? n : chunk) * R1;
+            if (need > a->vals_cap) {
+                MLMC_HIP_CHECK(hipStreamSynchronize(st));
+                if (a->d_vals_f) (void)hipFree(a->d_vals_f);
+                if (a->d_vals_c) (void)hipFree(a->d_vals_c);
+                a->d_vals_f = a->d_vals_c = nullptr;
+                a->vals_cap = 0;
+                MLMC_HIP_CHECK(hipMalloc(&a->d_vals_f, need));
+                MLMC_HIP_CHECK(hipMalloc(&a->d_vals_c, need));
+                a->vals_cap = need;
+            }
+            rc = 0;
+            for (int64_t off = 0; off < n && !rc; off += chunk) {
+                const int64_t m_n = (n - off < chunk) ? n - off : chunk;
+                rc = launch_eval(a->basis, f_m + off, m_n, R1, a->d_vals_f);
+                if (!rc && c_m) rc = launch_eval(a->basis, c_m + off, m_n, R1, a->d_vals_c);
+                if (!rc) rc = launch_cov_from_values(a, level, m, a->d_vals_f, c_m ? a->d_vals_c : nullptr,
+                                                     d_mask ? d_mask + off : nullptr, m_n, count);
+            }
         } else {
             rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, count, false);
         }

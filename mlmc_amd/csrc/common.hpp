@@ -81,6 +81,7 @@ struct mlmc_accum {
     int64_t *d_pcounts = nullptr; size_t pcounts_cap = 0;
     double *d_stage_f = nullptr, *d_stage_c = nullptr; size_t stage_cap = 0;
     uint8_t *d_mask = nullptr; size_t mask_cap = 0;
+    double *d_vals_f = nullptr, *d_vals_c = nullptr; size_t vals_cap = 0;   // materialised moment values (COV of TransformedMoments)
     void *d_out = nullptr;        // finalize outputs, one allocation: n[L] | n_rm[L] (int64) | n, n_rm as fp64 [2L] | s[L*K] | sp[L*K]
     size_t out_bytes = 0;
     void *h_out = nullptr;        // pinned host mirror of d_out
@@ -106,6 +107,8 @@ int launch_moments_finalize(mlmc_accum *a);
 int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
                      int64_t n, bool count, bool diff_gram_only);
 int launch_cov_finalize(mlmc_accum *a);
+int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_vf, const double *d_vc, const uint8_t *d_mask,
+                           int64_t n, bool count);
 int ensure(void **p, size_t *cap, size_t bytes);
 int timing_begin(mlmc_accum *a);
 int timing_end(mlmc_accum *a);

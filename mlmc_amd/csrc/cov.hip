@@ -26,7 +26,9 @@ constexpr int COV_LDS_STRIDE = 66;   // doubles per term row: == 2 (mod 32) -> d
 // MODE 0: G0, G1, G2 (covariance mean + variance);  MODE 1: G = D^T D only (variance of transformed moments)
 // BI, BJ (T = 4 only): the 64 x 64 output block (rows = terms [64 BI, 64 BI + 64), columns = terms [64 BJ, ...)) of
 // a covariance with more than 64 moments; off-diagonal blocks keep two term windows in LDS (one workgroup per CU).
-template <int KIND, int T, bool PAIR, int MODE, int BI = 0, int BJ = 0>
+// VALS: `fine` / `coarse` hold already evaluated moment values [n][R] (row-major, NaN rows = masked samples) instead
+// of raw samples: the path for moment functions that are not evaluated in registers (TransformedMoments).
+template <int KIND, int T, bool PAIR, int MODE, int BI = 0, int BJ = 0, bool VALS = false>
 __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisParams bp, const double *__restrict__ coef,
                                                       const double *__restrict__ fine,
                                                       const double *__restrict__ coarse,
@@ -68,13 +70,27 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
     int64_t batch = blockIdx.x;
     double xv = 0.0;
     uint8_t mv = 1;
-    if (evaluator && batch < n_batches) {
+    if (!VALS && evaluator && batch < n_batches) {
         int64_t idx = batch * COV_BATCH + samp;
         if (idx < n) { xv = src[idx]; if (mask) mv = mask[idx]; }
     }
     for (; batch < n_batches; batch += gridDim.x) {
         // ---------------- phase 1: moment values of this batch -> LDS ----------------
-        if (evaluator) {
+        if (VALS) {
+            if (evaluator) {
+                const int64_t idx = batch * COV_BATCH + samp;
+                const bool valid = idx < n;
+                const double *__restrict__ row = src + idx * (int64_t)R;
+                bool keep = valid && (!mask || mask[idx] != 0);
+                if (keep) { const double v0 = row[0]; keep = !(v0 != v0); }      // a masked value is NaN in every column
+                if (PAIR) {
+                    const int other = __shfl_xor((int)keep, 32, 64);
+                    keep = keep && (other != 0);
+                }
+                if (!is_coarse) { n_keep += (int)keep; n_rm += (int)(valid && !keep); }
+                for (int i = 0; i < NT; ++i) dst[i * COV_LDS_STRIDE + samp] = (keep && i < R) ? row[i] : 0.0;
+            }
+        } else if (evaluator) {
             const int64_t idx = batch * COV_BATCH + samp;
             const bool valid = idx < n;
             bool keep;
@@ -428,6 +444,49 @@ static int launch_cov_kind(const BasisParams &bp, int T, int bi, int bj, bool pa
     return fail("covariance: at most 128 moments");
 }
 
+// Covariance accumulation from materialised moment values [n][R1] (TransformedMoments): the generic kernel with VALS.
+int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_vf, const double *d_vc, const uint8_t *d_mask,
+                           int64_t n, bool count) {
+    if (n == 0) return 0;
+    const int R = a->Rout;
+    if (R > 64) return fail("covariance of TransformedMoments supports at most 64 moments on the device path");
+    hipStream_t st = rt().stream;
+    const int T = (R <= 16) ? 1 : (R <= 32 ? 2 : 4);
+    const int NT = 16 * T, NSL = 4 / T;
+    const bool pair = d_vc != nullptr;
+    const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
+    const size_t width = (size_t)3 * NT * NT;
+    int blocks = rt().n_cu * 2;
+    if (n_batches < blocks) blocks = (int)n_batches;
+    if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * NSL * width)) return rc;
+    if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
+    int64_t *pc = count ? a->d_pcounts : nullptr;
+    const BasisParams &bp = a->basis->p;
+#define MLMC_COV_VALS(TT)                                                                                                       \
+    do {                                                                                                                        \
+        if (pair)                                                                                                               \
+            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, true, 0, 0, 0, true>), dim3(blocks), dim3(256), 0, st, bp, nullptr,  \
+                               d_vf, d_vc, d_mask, n, R, a->d_partials, pc);                                                    \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, false, 0, 0, 0, true>), dim3(blocks), dim3(256), 0, st, bp, nullptr, \
+                               d_vf, d_vc, d_mask, n, R, a->d_partials, pc);                                                    \
+    } while (0)
+    if (T == 1) MLMC_COV_VALS(1);
+    else if (T == 2) MLMC_COV_VALS(2);
+    else MLMC_COV_VALS(4);
+#undef MLMC_COV_VALS
+    MLMC_HIP_CHECK(hipGetLastError());
+    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
+    hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, a->d_partials, blocks * NSL, NT, 3, a->RP, 0,
+                       0, totals);
+    MLMC_HIP_CHECK(hipGetLastError());
+    if (count) {
+        hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
+        MLMC_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
 int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
                      int64_t n, bool count, bool diff_gram_only) {
     if (n == 0) return 0;
@@ -502,7 +561,7 @@ __global__ void k_cov_finalize(const double *__restrict__ totals, const double *
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= R * R) return;
     const int i = idx / R, j = idx % R;
-    const double ci = scale_c[i], cj = scale_c[j];
+    const double ci = scale_c ? scale_c[i] : 1.0, cj = scale_c ? scale_c[j] : 1.0;   // nullptr: sums of true values
     const double cc = ci * cj;
     out_s[(int64_t)lc * R * R + idx] = 0.5 * cc * (G0[i * RP + j] + G0[j * RP + i]);
     out_sp[(int64_t)lc * R * R + idx] = 0.25 * (cc * cc) * ((G1[i * RP + j] + G1[j * RP + i]) + 2.0 * G2[i * RP + j]);
@@ -510,8 +569,10 @@ __global__ void k_cov_finalize(const double *__restrict__ totals, const double *
 
 int launch_cov_finalize(mlmc_accum *a) {
     const int n_lc = a->n_levels * a->n_comp;
-    const int R = a->R;
-    hipLaunchKernelGGL(k_cov_finalize, dim3((R * R + 255) / 256, n_lc), dim3(256), 0, rt().stream, a->d_totals, a->basis->d_scale, R,
+    const bool vals = a->basis->out_size > 0;          // covariance of TransformedMoments: accumulated from true values
+    const int R = vals ? a->Rout : a->R;
+    hipLaunchKernelGGL(k_cov_finalize, dim3((R * R + 255) / 256, n_lc), dim3(256), 0, rt().stream, a->d_totals,
+                       vals ? (const double *)nullptr : a->basis->d_scale, R,
                        a->RP, a->int_width, a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n, a->d_out_nd);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;

@@ -558,3 +558,21 @@ def test_spline_moments(hip):
     n, n_rm, s, sp = _run_accum(Spline(24, dom), lv, mode=LevelAccumulator.COV)
     ref = onp.estimate_mean(to_chunks(lv), lambda x: onp.covariance_rows(b, x))
     _check_against(n, n_rm, s, sp, ref)
+
+
+def test_covariance_of_transformed_moments(hip):
+    """estimate_covariance with a TransformedMoments basis: transformed values are materialised chunk-wise on the device
+    and fed to the MFMA covariance kernel; against the oracle (reference form, per-sample matrix product)."""
+    from mlmc_amd import Legendre, TransformedMoments
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-3.7, 3.7)
+    levels = level_arrays([3000, 2001, 700], [0.5, 0.07, 0.01], 1, 9)
+    rng = np.random.default_rng(8)
+    for R0, R1 in ((9, 6), (33, 33), (64, 40)):
+        mat = rng.normal(size=(R1, R0)) / np.sqrt(R0)
+        mat[0] = 0
+        mat[0, 0] = 1
+        n, n_rm, s, sp = _run_accum(TransformedMoments(Legendre(R0, dom), mat), levels, mode=LevelAccumulator.COV)
+        bt = onp.Basis(onp.LEGENDRE, R0, dom, matrix=mat)
+        ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.covariance_rows(bt, x))
+        _check_against(n, n_rm, s, sp, ref)
