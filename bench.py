@@ -228,13 +228,13 @@ def pdf_solve_timing(fn, L, data, LevelAccumulator, level_stats):
     acc = LevelAccumulator(fn, L, LevelAccumulator.COV)
     for l in range(L):
         acc.push(l, data[l][0], data[l][1])
-    n, _, s, _ = acc.finalize()
+    n, _, s, _ = acc.finalize(reduce=False)      # rank-local: only rank 0 runs this chain, no collective
     cov = np.sum(s / n[:, None], axis=0).reshape(fn.size, fn.size)
     ortho, info = sd.construct_ortogonal_moments(fn, cov, tol=1e-4)
     acc2 = LevelAccumulator(ortho, L, LevelAccumulator.MOMENTS)
     for l in range(L):
         acc2.push(l, data[l][0], data[l][1])
-    n2, _, s2, _ = acc2.finalize()
+    n2, _, s2, _ = acc2.finalize(reduce=False)
     means = np.sum(s2 / n2[:, None], axis=0)
     t1 = time.perf_counter()
     distr = sd.SimpleDistribution(ortho, np.stack([means, np.ones_like(means)], axis=1), domain=fn.domain)

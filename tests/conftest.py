@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The shared libraries are build artefacts (git-ignored): build them when a fresh checkout has none."""
+    if not os.path.exists(os.path.join(ROOT, "mlmc_amd", "libmlmc_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
