@@ -78,8 +78,15 @@ def main():
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # RCCL logs to stdout by default; stdout carries the JSON line
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # MLMC_BENCH_BACKEND=gloo / MLMC_BENCH_DEVICE=0: rehearse the multi-rank flow on a one-GPU box (tests only)
+        backend = os.environ.get("MLMC_BENCH_BACKEND", "nccl")
+        if "MLMC_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["MLMC_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
 
     from mlmc_amd import _lib, Legendre, Spline
