@@ -306,3 +306,25 @@ def test_estimate_domain(hip):
     assert lo == ref[0] and hi == ref[1]
     lo2, hi2 = Estimate.estimate_domain(q, st)
     assert lo2 == lo and hi2 == hi
+
+
+def test_covariance_layouts_of_vector_quantity(hip):
+    """covariance(q, fn, cov_at_bottom=True/False) of an M = 4 quantity: result shapes and row order as in the reference
+    (quantity_estimate.py:143-156), values against the oracle."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from tests.util import to_chunks
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    steps = [0.5, 0.07]
+    levels = level_arrays([900, 700], steps, 4, 11)
+    st = _storage(levels, steps, _vec_spec())
+    q = make_root_quantity(st, _vec_spec())['q']
+    fn = Legendre(5, dom)
+    b = onp.Basis(onp.LEGENDRE, 5, dom)
+    for bottom in (True, False):
+        r = qe.estimate_mean(qe.covariance(q, fn, cov_at_bottom=bottom))
+        ref = onp.estimate_mean(to_chunks(levels), lambda v: onp.covariance_rows(b, v, bottom))
+        assert np.array_equal(r.n_samples, ref.n_samples) and np.array_equal(r.n_rm_samples, ref.n_rm_samples)
+        assert r.mean.size == ref.mean.size == 4 * 25
+        assert close(r.mean.ravel(), ref.mean, 1.0, TOL) and close(r.var.ravel(), ref.var, None, TOL)

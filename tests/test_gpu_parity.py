@@ -576,3 +576,42 @@ def test_covariance_of_transformed_moments(hip):
         bt = onp.Basis(onp.LEGENDRE, R0, dom, matrix=mat)
         ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.covariance_rows(bt, x))
         _check_against(n, n_rm, s, sp, ref)
+
+
+def test_log_transform_and_other_families_accumulate(hip):
+    """log=True moments (device log), Monomial / Fourier covariance, multi-component covariance."""
+    from mlmc_amd import Fourier, Legendre, Monomial
+    from mlmc_amd.engine import LevelAccumulator
+    rng = np.random.default_rng(21)
+    # log-normal samples, log-domain Legendre / Monomial moments
+    x = rng.lognormal(mean=0.3, sigma=0.8, size=20011)
+    f1 = x * (1 + 0.01 * rng.normal(size=x.size))
+    c1 = x * (1 + 0.03 * rng.normal(size=x.size))
+    f1[::501] = -1.0                                     # log of a non-positive value -> NaN -> masked
+    levels = [(x[None], None), (f1[None], c1[None])]
+    ldom = (0.05, 30.0)
+    for cls, kind, R in ((Legendre, onp.LEGENDRE, 12), (Monomial, onp.MONOMIAL, 6)):
+        n, n_rm, s, sp = _run_accum(cls(R, ldom, log=True), levels)
+        b = onp.Basis(kind, R, ldom, log=True)
+        ref = onp.estimate_mean(to_chunks(levels), lambda v: onp.moments_rows(b, v))
+        _check_against(n, n_rm, s, sp, ref)
+    # Monomial and Fourier covariance
+    dom = (-3.7, 3.7)
+    lv = level_arrays([2500, 1500], [0.3, 0.02], 1, 7)
+    for cls, kind, R in ((Monomial, onp.MONOMIAL, 7), (Fourier, onp.FOURIER, 9)):
+        n, n_rm, s, sp = _run_accum(cls(R, dom), lv, mode=LevelAccumulator.COV)
+        b = onp.Basis(kind, R, dom)
+
+        def rows(v, b=b, R=R):
+            phi = onp.eval_all(b, v.reshape(-1)).reshape(v.shape + (R,))
+            phi[np.isnan(phi).any(axis=-1)] = np.nan
+            cov = np.einsum('...i,...j', phi, phi)                   # [M, n, 2|1, R, R]
+            return cov.transpose((0, 3, 4, 1, 2)).reshape(R * R, v.shape[1], v.shape[2])
+        ref = onp.estimate_mean(to_chunks(lv), rows)
+        _check_against(n, n_rm, s, sp, ref)
+    # covariance of a 3-component quantity (a sample is dropped when any component is masked)
+    lv3 = level_arrays([1800, 1100], [0.3, 0.02], 3, 6)
+    n, n_rm, s, sp = _run_accum(Legendre(10, dom), lv3, mode=LevelAccumulator.COV, n_comp=3)
+    b = onp.Basis(onp.LEGENDRE, 10, dom)
+    ref = onp.estimate_mean(to_chunks(lv3), lambda v: onp.covariance_rows(b, v))
+    _check_against(n, n_rm, s, sp, ref)
