@@ -153,21 +153,15 @@ int mlmc_basis_create(const mlmc_basis_desc *d, mlmc_basis **out) {
     b->p.is_clip = d->is_clip;
     b->out_size = d->out_size;
     const int R = d->size;
-    std::vector<double> coef(R, 0.0);
     b->scale_c.assign(R, 1.0);
     if (d->kind == MLMC_LEGENDRE) {
         long double c = 1.0L;   // leading coefficient of P_i: c_i = c_{i-1} (2i-1)/i
         for (int i = 0; i < R; ++i) {
-            if (i >= 2) {
-                c = c * (long double)(2 * i - 1) / (long double)i;
-                coef[i] = (double)(((long double)(i - 1) * (i - 1)) / ((long double)(2 * i - 1) * (2 * i - 3)));
-            }
+            if (i >= 2) c = c * (long double)(2 * i - 1) / (long double)i;
             b->scale_c[i] = (double)c;
         }
     }
-    MLMC_HIP_CHECK(hipMalloc(&b->d_coef, sizeof(double) * R));
     MLMC_HIP_CHECK(hipMalloc(&b->d_scale, sizeof(double) * R));
-    MLMC_HIP_CHECK(hipMemcpy(b->d_coef, coef.data(), sizeof(double) * R, hipMemcpyHostToDevice));
     MLMC_HIP_CHECK(hipMemcpy(b->d_scale, b->scale_c.data(), sizeof(double) * R, hipMemcpyHostToDevice));
     if (d->out_size > 0) {
         b->matrix.assign(d->matrix, d->matrix + (size_t)d->out_size * R);
@@ -180,7 +174,6 @@ int mlmc_basis_create(const mlmc_basis_desc *d, mlmc_basis **out) {
 
 void mlmc_basis_destroy(mlmc_basis *b) {
     if (!b) return;
-    if (b->d_coef) (void)hipFree(b->d_coef);
     if (b->d_scale) (void)hipFree(b->d_scale);
     if (b->d_matrix) (void)hipFree(b->d_matrix);
     delete b;

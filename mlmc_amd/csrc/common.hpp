@@ -49,7 +49,6 @@ struct mlmc_basis {
     int out_size = 0;                 // 0 = no transform
     std::vector<double> matrix;       // [out_size][size] host copy
     std::vector<double> scale_c;      // host: P_i = scale_c[i] * Q_i (Legendre: leading coefficients; else 1)
-    double *d_coef = nullptr;         // device: recurrence coefficients g_i [size]
     double *d_scale = nullptr;        // device: scale_c [size]
     double *d_matrix = nullptr;       // device: matrix [out_size][size]
 };

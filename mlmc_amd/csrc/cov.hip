@@ -29,7 +29,7 @@ constexpr int COV_LDS_STRIDE = 66;   // doubles per term row: == 2 (mod 32) -> d
 // VALS: `fine` / `coarse` hold already evaluated moment values [n][R] (row-major, NaN rows = masked samples) instead
 // of raw samples: the path for moment functions that are not evaluated in registers (TransformedMoments).
 template <int KIND, int T, bool PAIR, int MODE, int BI = 0, int BJ = 0, bool VALS = false>
-__global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisParams bp, const double *__restrict__ coef,
+__global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisParams bp, 
                                                       const double *__restrict__ fine,
                                                       const double *__restrict__ coarse,
                                                       const uint8_t *__restrict__ mask, int64_t n, int R,
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
             // never read back
 #pragma unroll
             for (int i = 0; i < N_EVAL; ++i) {
-                const double q = g.next(i, coef);
+                const double q = g.next(i);
                 if (i >= TA && i < TA + NT) dst[(i - TA) * COV_LDS_STRIDE + samp] = q;
                 if (WIDE && i >= TB && i < TB + NT) dst_b[(i - TB) * COV_LDS_STRIDE + samp] = q;
             }
@@ -208,7 +208,7 @@ __host__ __device__ constexpr int sym_j(int w, int t) {
 }
 
 template <int KIND, bool PAIR, int MODE, int BD, int W>
-__device__ __forceinline__ void cov_t4_body(const BasisParams &bp, const double *__restrict__ coef,
+__device__ __forceinline__ void cov_t4_body(const BasisParams &bp, 
                                             const double *__restrict__ fine, const double *__restrict__ coarse,
                                             const uint8_t *__restrict__ mask, int64_t n, double *__restrict__ partials,
                                             int64_t *__restrict__ pcounts, double *__restrict__ lds_f,
@@ -265,7 +265,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp, const double 
             g.init(keep ? t : 0.0, keep ? 1.0 : 0.0, bp);
 #pragma unroll
             for (int i = 0; i < N_EVAL; ++i) {
-                const double q = g.next(i, coef);
+                const double q = g.next(i);
                 if (i >= TA) dst[(i - TA) * COV_LDS_STRIDE + samp] = q;
             }
         }
@@ -365,7 +365,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp, const double 
 }
 
 template <int KIND, bool PAIR, int MODE, int BD>
-__global__ __launch_bounds__(256, 2) void k_cov_accum_t4(BasisParams bp, const double *__restrict__ coef,
+__global__ __launch_bounds__(256, 2) void k_cov_accum_t4(BasisParams bp, 
                                                          const double *__restrict__ fine, const double *__restrict__ coarse,
                                                          const uint8_t *__restrict__ mask, int64_t n, int R,
                                                          double *__restrict__ partials, int64_t *__restrict__ pcounts) {
@@ -374,10 +374,10 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum_t4(BasisParams bp, const d
     __shared__ int ldc[2][2];
     (void)R;
     switch (threadIdx.x >> 6) {   // every wave runs its own specialisation (same barrier count in all of them)
-        case 0: cov_t4_body<KIND, PAIR, MODE, BD, 0>(bp, coef, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
-        case 1: cov_t4_body<KIND, PAIR, MODE, BD, 1>(bp, coef, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
-        case 2: cov_t4_body<KIND, PAIR, MODE, BD, 2>(bp, coef, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
-        default: cov_t4_body<KIND, PAIR, MODE, BD, 3>(bp, coef, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
+        case 0: cov_t4_body<KIND, PAIR, MODE, BD, 0>(bp, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
+        case 1: cov_t4_body<KIND, PAIR, MODE, BD, 1>(bp, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
+        case 2: cov_t4_body<KIND, PAIR, MODE, BD, 2>(bp, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
+        default: cov_t4_body<KIND, PAIR, MODE, BD, 3>(bp, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
     }
 }
 
@@ -411,29 +411,29 @@ __global__ void k_reduce_counts2(const int64_t *__restrict__ pcounts, int nblock
 }
 
 template <int KIND, int T, int MODE, int BI, int BJ>
-static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, const double *coef, const double *d_f, const double *d_c,
+static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, const double *d_f, const double *d_c,
                         const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
     hipStream_t st = rt().stream;
     if constexpr (T == 4 && BI == BJ) {   // diagonal 64 x 64 block: symmetric, wave-specialised kernel
         if (pair)
-            hipLaunchKernelGGL((k_cov_accum_t4<KIND, true, MODE, BI>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+            hipLaunchKernelGGL((k_cov_accum_t4<KIND, true, MODE, BI>), dim3(blocks), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
         else
-            hipLaunchKernelGGL((k_cov_accum_t4<KIND, false, MODE, BI>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+            hipLaunchKernelGGL((k_cov_accum_t4<KIND, false, MODE, BI>), dim3(blocks), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
         MLMC_HIP_CHECK(hipGetLastError());
         return 0;
     }
     if (pair)
-        hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE, BI, BJ>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+        hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE, BI, BJ>), dim3(blocks), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
     else
-        hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE, BI, BJ>), dim3(blocks), dim3(256), 0, st, bp, coef, d_f, d_c, d_mask, n, R, partials, pcounts);
+        hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE, BI, BJ>), dim3(blocks), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 template <int KIND, int MODE>
-static int launch_cov_kind(const BasisParams &bp, int T, int bi, int bj, bool pair, int blocks, const double *coef, const double *d_f,
+static int launch_cov_kind(const BasisParams &bp, int T, int bi, int bj, bool pair, int blocks, const double *d_f,
                            const double *d_c, const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
-#define MLMC_COV_ARGS bp, pair, blocks, coef, d_f, d_c, d_mask, n, R, partials, pcounts
+#define MLMC_COV_ARGS bp, pair, blocks, d_f, d_c, d_mask, n, R, partials, pcounts
     if (T == 1) return launch_cov_t<KIND, 1, MODE, 0, 0>(MLMC_COV_ARGS);
     if (T == 2) return launch_cov_t<KIND, 2, MODE, 0, 0>(MLMC_COV_ARGS);
     if (bi == 0 && bj == 0) return launch_cov_t<KIND, 4, MODE, 0, 0>(MLMC_COV_ARGS);
@@ -465,10 +465,10 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
 #define MLMC_COV_VALS(TT)                                                                                                       \
     do {                                                                                                                        \
         if (pair)                                                                                                               \
-            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, true, 0, 0, 0, true>), dim3(blocks), dim3(256), 0, st, bp, nullptr,  \
+            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, true, 0, 0, 0, true>), dim3(blocks), dim3(256), 0, st, bp,           \
                                d_vf, d_vc, d_mask, n, R, a->d_partials, pc);                                                    \
         else                                                                                                                    \
-            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, false, 0, 0, 0, true>), dim3(blocks), dim3(256), 0, st, bp, nullptr, \
+            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, false, 0, 0, 0, true>), dim3(blocks), dim3(256), 0, st, bp,          \
                                d_vf, d_vc, d_mask, n, R, a->d_partials, pc);                                                    \
     } while (0)
     if (T == 1) MLMC_COV_VALS(1);
@@ -501,7 +501,6 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
     const size_t width = (size_t)NG * NT * NT;
     const BasisParams &bp = a->basis->p;
-    const double *coef = a->basis->d_coef;
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0);
     for (int bi = 0; bi < NB; ++bi)
         for (int bj = 0; bj < NB; ++bj) {
@@ -515,8 +514,8 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
             if (timed) if (int rc = timing_begin(a)) return rc;
             int rc;
 #define MLMC_COV_DISPATCH(KIND)                                                                                               \
-    rc = diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, bi, bj, pair, blocks, coef, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
-                        : launch_cov_kind<KIND, 0>(bp, T, bi, bj, pair, blocks, coef, d_f, d_c, d_mask, n, R, a->d_partials, pc)
+    rc = diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, bi, bj, pair, blocks, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
+                        : launch_cov_kind<KIND, 0>(bp, T, bi, bj, pair, blocks, d_f, d_c, d_mask, n, R, a->d_partials, pc)
             switch (bp.kind) {
                 case MLMC_LEGENDRE: MLMC_COV_DISPATCH(MLMC_LEGENDRE); break;
                 case MLMC_MONOMIAL: MLMC_COV_DISPATCH(MLMC_MONOMIAL); break;

@@ -59,7 +59,7 @@ struct TermGen {
         }
     }
     // must be called with i = 0, 1, 2, ... in order
-    __device__ __forceinline__ double next(int i, const double *__restrict__ coef) {
+    __device__ __forceinline__ double next(int i) {
         if (i == 0) return p1;
         if (KIND == MLMC_LEGENDRE) {
             double q;
@@ -91,7 +91,7 @@ template <>
 struct TermGen<MLMC_IDENTITY> {
     double v;
     __device__ __forceinline__ void init(double x_, double w, const BasisParams &) { v = x_ * w; }
-    __device__ __forceinline__ double next(int, const double *__restrict__) { return v; }
+    __device__ __forceinline__ double next(int) { return v; }
 };
 
 // SPLINE: phi_0 = 1, phi_r = B_r(t), r >= 1, of the clamped uniform cubic B-spline basis B_0..B_{nb-1} on
@@ -132,7 +132,7 @@ struct TermGen<MLMC_SPLINE> {
         }
         n0 = N[0] * w; n1 = N[1] * w; n2 = N[2] * w; n3 = N[3] * w;
     }
-    __device__ __forceinline__ double next(int i, const double *__restrict__) {
+    __device__ __forceinline__ double next(int i) {
         if (i == 0) return w;
         const int j = i - k;
         return j == 0 ? n0 : (j == 1 ? n1 : (j == 2 ? n2 : (j == 3 ? n3 : 0.0)));

@@ -229,7 +229,7 @@ __global__ void k_me_scale_cols(double *__restrict__ Phi, const double *__restri
 
 // density(x) = exp(clip(-sum_r c_r Q_r(x), +-200)), c = effective coefficients in the underlying (scaled) family
 template <int KIND>
-__global__ void k_density(BasisParams bp, const double *__restrict__ coef, const double *__restrict__ c, int R,
+__global__ void k_density(BasisParams bp, const double *__restrict__ c, int R,
                           const double *__restrict__ x, int64_t n, double *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -238,14 +238,14 @@ __global__ void k_density(BasisParams bp, const double *__restrict__ coef, const
     TermGen<KIND> g;
     g.init(keep ? t : 0.0, 1.0, bp);
     double power = 0.0;
-    for (int r = 0; r < R; ++r) power = __builtin_fma(g.next(r, coef), c[r], power);
+    for (int r = 0; r < R; ++r) power = __builtin_fma(g.next(r), c[r], power);
     power = fmin(fmax(-power, -200.0), 200.0);
     out[i] = keep ? exp(power) : __builtin_nan("");
 }
 
 // integral of the density over [lo_i, hi_i] with a `deg`-point Gauss-Legendre rule (nodes/weights on [-1, 1])
 template <int KIND>
-__global__ void k_density_integrate(BasisParams bp, const double *__restrict__ coef, const double *__restrict__ c, int R,
+__global__ void k_density_integrate(BasisParams bp, const double *__restrict__ c, int R,
                                     const double *__restrict__ lo, const double *__restrict__ hi, int64_t n,
                                     const double *__restrict__ nodes, const double *__restrict__ wts, int deg,
                                     double *__restrict__ out) {
@@ -260,7 +260,7 @@ __global__ void k_density_integrate(BasisParams bp, const double *__restrict__ c
         TermGen<KIND> g;
         g.init(keep ? t : 0.0, 1.0, bp);
         double power = 0.0;
-        for (int r = 0; r < R; ++r) power = __builtin_fma(g.next(r, coef), c[r], power);
+        for (int r = 0; r < R; ++r) power = __builtin_fma(g.next(r), c[r], power);
         power = fmin(fmax(-power, -200.0), 200.0);
         acc = __builtin_fma(wts[k], keep ? exp(power) : __builtin_nan(""), acc);
     }
@@ -528,10 +528,10 @@ int mlmc_density_eval(const mlmc_basis *b, const double *lambda, const double *s
     }
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     switch (b->p.kind) {
-        case MLMC_LEGENDRE: hipLaunchKernelGGL(k_density<MLMC_LEGENDRE>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, xd, n, od); break;
-        case MLMC_MONOMIAL: hipLaunchKernelGGL(k_density<MLMC_MONOMIAL>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, xd, n, od); break;
-        case MLMC_FOURIER: hipLaunchKernelGGL(k_density<MLMC_FOURIER>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, xd, n, od); break;
-        case MLMC_SPLINE: hipLaunchKernelGGL(k_density<MLMC_SPLINE>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, xd, n, od); break;
+        case MLMC_LEGENDRE: hipLaunchKernelGGL(k_density<MLMC_LEGENDRE>, grid, block, 0, st, b->p, d_c.d(), Reff, xd, n, od); break;
+        case MLMC_MONOMIAL: hipLaunchKernelGGL(k_density<MLMC_MONOMIAL>, grid, block, 0, st, b->p, d_c.d(), Reff, xd, n, od); break;
+        case MLMC_FOURIER: hipLaunchKernelGGL(k_density<MLMC_FOURIER>, grid, block, 0, st, b->p, d_c.d(), Reff, xd, n, od); break;
+        case MLMC_SPLINE: hipLaunchKernelGGL(k_density<MLMC_SPLINE>, grid, block, 0, st, b->p, d_c.d(), Reff, xd, n, od); break;
         default: return fail("mlmc_density_eval: unsupported basis kind");
     }
     MLMC_HIP_CHECK(hipGetLastError());
@@ -570,10 +570,10 @@ int mlmc_density_integrate(const mlmc_basis *b, const double *lambda, const doub
     MLMC_HIP_CHECK(hipMemcpyAsync(d_gw.p, gw.data(), sizeof(double) * degree, hipMemcpyHostToDevice, st));
     const dim3 grid((unsigned)((n + 127) / 128)), block(128);
     switch (b->p.kind) {
-        case MLMC_LEGENDRE: hipLaunchKernelGGL(k_density_integrate<MLMC_LEGENDRE>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
-        case MLMC_MONOMIAL: hipLaunchKernelGGL(k_density_integrate<MLMC_MONOMIAL>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
-        case MLMC_FOURIER: hipLaunchKernelGGL(k_density_integrate<MLMC_FOURIER>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
-        case MLMC_SPLINE: hipLaunchKernelGGL(k_density_integrate<MLMC_SPLINE>, grid, block, 0, st, b->p, b->d_coef, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
+        case MLMC_LEGENDRE: hipLaunchKernelGGL(k_density_integrate<MLMC_LEGENDRE>, grid, block, 0, st, b->p, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
+        case MLMC_MONOMIAL: hipLaunchKernelGGL(k_density_integrate<MLMC_MONOMIAL>, grid, block, 0, st, b->p, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
+        case MLMC_FOURIER: hipLaunchKernelGGL(k_density_integrate<MLMC_FOURIER>, grid, block, 0, st, b->p, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
+        case MLMC_SPLINE: hipLaunchKernelGGL(k_density_integrate<MLMC_SPLINE>, grid, block, 0, st, b->p, d_c.d(), Reff, d_lo.d(), d_hi.d(), n, d_gx.d(), d_gw.d(), degree, d_o.d()); break;
         default: return fail("mlmc_density_integrate: unsupported basis kind");
     }
     MLMC_HIP_CHECK(hipGetLastError());

@@ -21,7 +21,7 @@ namespace mlmc {
 // callers, plots and tests.  One thread per value.
 // ------------------------------------------------------------------------------------------
 template <int KIND>
-__global__ void k_eval(BasisParams bp, const double *__restrict__ coef, const double *__restrict__ scale_c,
+__global__ void k_eval(BasisParams bp, const double *__restrict__ scale_c,
                        const double *__restrict__ x, int64_t n, int size, double *__restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -31,7 +31,7 @@ __global__ void k_eval(BasisParams bp, const double *__restrict__ coef, const do
     g.init(keep ? t : 0.0, 1.0, bp);
     const double nan = __builtin_nan("");
     for (int r = 0; r < size; ++r) {
-        double q = g.next(r, coef);
+        double q = g.next(r);
         if (KIND == MLMC_LEGENDRE) q *= scale_c[r];
         out[i * size + r] = keep ? q : nan;
     }
@@ -64,11 +64,11 @@ int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, dou
         target = d_tmp;
     }
     switch (bp.kind) {
-        case MLMC_LEGENDRE: hipLaunchKernelGGL(k_eval<MLMC_LEGENDRE>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
-        case MLMC_MONOMIAL: hipLaunchKernelGGL(k_eval<MLMC_MONOMIAL>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
-        case MLMC_FOURIER: hipLaunchKernelGGL(k_eval<MLMC_FOURIER>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
-        case MLMC_IDENTITY: hipLaunchKernelGGL(k_eval<MLMC_IDENTITY>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
-        case MLMC_SPLINE: hipLaunchKernelGGL(k_eval<MLMC_SPLINE>, dim3(blocks), dim3(threads), 0, st, bp, b->d_coef, b->d_scale, d_x, n, esize, target); break;
+        case MLMC_LEGENDRE: hipLaunchKernelGGL(k_eval<MLMC_LEGENDRE>, dim3(blocks), dim3(threads), 0, st, bp, b->d_scale, d_x, n, esize, target); break;
+        case MLMC_MONOMIAL: hipLaunchKernelGGL(k_eval<MLMC_MONOMIAL>, dim3(blocks), dim3(threads), 0, st, bp, b->d_scale, d_x, n, esize, target); break;
+        case MLMC_FOURIER: hipLaunchKernelGGL(k_eval<MLMC_FOURIER>, dim3(blocks), dim3(threads), 0, st, bp, b->d_scale, d_x, n, esize, target); break;
+        case MLMC_IDENTITY: hipLaunchKernelGGL(k_eval<MLMC_IDENTITY>, dim3(blocks), dim3(threads), 0, st, bp, b->d_scale, d_x, n, esize, target); break;
+        case MLMC_SPLINE: hipLaunchKernelGGL(k_eval<MLMC_SPLINE>, dim3(blocks), dim3(threads), 0, st, bp, b->d_scale, d_x, n, esize, target); break;
         default: return fail("unknown basis kind");
     }
     MLMC_HIP_CHECK(hipGetLastError());
@@ -150,7 +150,7 @@ struct ReduceTable {
 };
 
 template <int KIND, int RT, bool PAIR, bool FIRST>
-__device__ __forceinline__ void accum_samples(const BasisParams &bp, const double *__restrict__ coef,
+__device__ __forceinline__ void accum_samples(const BasisParams &bp, 
                                               const double *__restrict__ fine, const double *__restrict__ coarse,
                                               const uint8_t *__restrict__ mask, int64_t n, int t0, int bid, int nb,
                                               double (&s)[RT], double (&sp)[RT], int &n_keep, int &n_rm) {
@@ -190,15 +190,15 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp, const doubl
 
         if (!FIRST) {   // later passes of R > 64: advance the recurrences without accumulating
             for (int i = 0; i < t0; ++i) {
-                gf0.next(i, coef); gf1.next(i, coef);
-                if (PAIR) { gc0.next(i, coef); gc1.next(i, coef); }
+                gf0.next(i); gf1.next(i);
+                if (PAIR) { gc0.next(i); gc1.next(i); }
             }
         }
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-            double d0 = gf0.next(t0 + i, coef);
-            double d1 = gf1.next(t0 + i, coef);
-            if (PAIR) { d0 -= gc0.next(t0 + i, coef); d1 -= gc1.next(t0 + i, coef); }
+            double d0 = gf0.next(t0 + i);
+            double d1 = gf1.next(t0 + i);
+            if (PAIR) { d0 -= gc0.next(t0 + i); d1 -= gc1.next(t0 + i); }
             s[i] += d0;
             sp[i] = __builtin_fma(d0, d0, sp[i]);
             s[i] += d1;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp, const doubl
 }
 
 template <int KIND, int RT, bool FIRST>
-__global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, const double *__restrict__ coef, SegTable tab,
+__global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, SegTable tab,
                                                               int t0_arg, double *__restrict__ partials,
                                                               int64_t *__restrict__ pcounts) {
     const int t0 = FIRST ? 0 : t0_arg;
@@ -226,9 +226,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, c
     for (int i = 0; i < RT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
     int n_keep = 0, n_rm = 0;
     if (sg.coarse)
-        accum_samples<KIND, RT, true, FIRST>(bp, coef, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+        accum_samples<KIND, RT, true, FIRST>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
     else
-        accum_samples<KIND, RT, false, FIRST>(bp, coef, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+        accum_samples<KIND, RT, false, FIRST>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
 
     // ---- block partial: the four waves add their lanes' accumulators into one LDS image [value][lane] in a
     // fixed order, then one thread per value sums the 64 lanes (row stride 65: conflict-free both ways) ----
@@ -396,13 +396,13 @@ __global__ __launch_bounds__(ACC_THREADS) void k_spline_accum(BasisParams bp, Se
 }
 
 template <int KIND, int RT>
-static int launch_accum_rt(const BasisParams &bp, const double *coef, const SegTable &tab, int total_blocks, int t0,
+static int launch_accum_rt(const BasisParams &bp, const SegTable &tab, int total_blocks, int t0,
                            double *partials, int64_t *pcounts) {
     hipStream_t st = rt().stream;
     if (t0 == 0)
-        hipLaunchKernelGGL((k_moments_accum<KIND, RT, true>), dim3(total_blocks), dim3(ACC_THREADS), 0, st, bp, coef, tab, t0, partials, pcounts);
+        hipLaunchKernelGGL((k_moments_accum<KIND, RT, true>), dim3(total_blocks), dim3(ACC_THREADS), 0, st, bp, tab, t0, partials, pcounts);
     else
-        hipLaunchKernelGGL((k_moments_accum<KIND, RT, false>), dim3(total_blocks), dim3(ACC_THREADS), 0, st, bp, coef, tab, t0, partials, pcounts);
+        hipLaunchKernelGGL((k_moments_accum<KIND, RT, false>), dim3(total_blocks), dim3(ACC_THREADS), 0, st, bp, tab, t0, partials, pcounts);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -429,10 +429,10 @@ static int pick_rt(int kind, int n_terms) {
 }
 
 // op 0: *out = resident blocks per CU of the instantiation; op 1: launch
-static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const double *coef, const SegTable *tab, int total_blocks,
+static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const SegTable *tab, int total_blocks,
                           int t0, double *partials, int64_t *pcounts, int *out) {
 #define MLMC_RT_CASE(KIND, N) \
-    case N: return op == 0 ? occupancy_rt<KIND, N>(out) : launch_accum_rt<KIND, N>(bp, coef, *tab, total_blocks, t0, partials, pcounts)
+    case N: return op == 0 ? occupancy_rt<KIND, N>(out) : launch_accum_rt<KIND, N>(bp, *tab, total_blocks, t0, partials, pcounts)
     switch (bp.kind) {
         case MLMC_LEGENDRE:
             switch (rt_sel) {
@@ -441,23 +441,23 @@ static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const doubl
                 MLMC_RT_CASE(MLMC_LEGENDRE, 28); MLMC_RT_CASE(MLMC_LEGENDRE, 32); MLMC_RT_CASE(MLMC_LEGENDRE, 40);
                 MLMC_RT_CASE(MLMC_LEGENDRE, 48); MLMC_RT_CASE(MLMC_LEGENDRE, 56);
                 default: return op == 0 ? occupancy_rt<MLMC_LEGENDRE, 64>(out)
-                                        : launch_accum_rt<MLMC_LEGENDRE, 64>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
+                                        : launch_accum_rt<MLMC_LEGENDRE, 64>(bp, *tab, total_blocks, t0, partials, pcounts);
             }
         case MLMC_MONOMIAL:
             switch (rt_sel) {
                 MLMC_RT_CASE(MLMC_MONOMIAL, 8); MLMC_RT_CASE(MLMC_MONOMIAL, 16); MLMC_RT_CASE(MLMC_MONOMIAL, 32);
                 default: return op == 0 ? occupancy_rt<MLMC_MONOMIAL, 64>(out)
-                                        : launch_accum_rt<MLMC_MONOMIAL, 64>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
+                                        : launch_accum_rt<MLMC_MONOMIAL, 64>(bp, *tab, total_blocks, t0, partials, pcounts);
             }
         case MLMC_FOURIER:
             switch (rt_sel) {
                 MLMC_RT_CASE(MLMC_FOURIER, 8); MLMC_RT_CASE(MLMC_FOURIER, 16); MLMC_RT_CASE(MLMC_FOURIER, 32);
                 default: return op == 0 ? occupancy_rt<MLMC_FOURIER, 64>(out)
-                                        : launch_accum_rt<MLMC_FOURIER, 64>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
+                                        : launch_accum_rt<MLMC_FOURIER, 64>(bp, *tab, total_blocks, t0, partials, pcounts);
             }
         case MLMC_IDENTITY:
             return op == 0 ? occupancy_rt<MLMC_IDENTITY, 4>(out)
-                           : launch_accum_rt<MLMC_IDENTITY, 4>(bp, coef, *tab, total_blocks, t0, partials, pcounts);
+                           : launch_accum_rt<MLMC_IDENTITY, 4>(bp, *tab, total_blocks, t0, partials, pcounts);
         default: return fail("unknown basis kind");
     }
 #undef MLMC_RT_CASE
@@ -478,7 +478,7 @@ int flush_moments(mlmc_accum *a) {
         const int width = 2 * rt_sel;
         int per_cu = 4;
         if (!sparse_spline)
-            if (int rc = accum_dispatch(0, bp, rt_sel, nullptr, nullptr, 0, 0, nullptr, nullptr, &per_cu)) return rc;
+            if (int rc = accum_dispatch(0, bp, rt_sel, nullptr, 0, 0, nullptr, nullptr, &per_cu)) return rc;
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 4) per_cu = 4;
         const int resident = rt().n_cu * per_cu;
@@ -519,7 +519,7 @@ int flush_moments(mlmc_accum *a) {
             const size_t lds = sizeof(double) * 4 * 2 * (size_t)(R + 8);
             hipLaunchKernelGGL(k_spline_accum, dim3(total), dim3(ACC_THREADS), lds, st, bp, tab, R, a->d_partials, a->d_pcounts);
             MLMC_HIP_CHECK(hipGetLastError());
-        } else if (int rc = accum_dispatch(1, bp, rt_sel, a->basis->d_coef, &tab, total, t0, a->d_partials, a->d_pcounts, nullptr)) {
+        } else if (int rc = accum_dispatch(1, bp, rt_sel, &tab, total, t0, a->d_partials, a->d_pcounts, nullptr)) {
             return rc;
         }
         if (int rc = timing_end(a)) return rc;
