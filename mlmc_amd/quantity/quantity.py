@@ -43,6 +43,8 @@ class Quantity:
         self._selection_id = self.set_selection_id()
         self._check_selection_ids()
         self._memo = (None, {})
+        # a quantity whose chunks are not a pure function of the stored samples (random sub-sampling below it)
+        self._volatile = any(getattr(q, "_volatile", False) for q in self._input_quantities)
 
     # ---- structure ---------------------------------------------------------------------------
     def get_quantity_storage(self):
@@ -230,8 +232,10 @@ class Quantity:
             p.k, p.n, p.total_n = p._orig_k, p._orig_n, p._orig_total_n
             return p
         params_q._adjust_value = adjust_value
-        return Quantity(quantity_type=self.qtype.replace_scalar(qt.BoolType()), input_quantities=[self, params_q],
-                        operation=Quantity.pick_samples)
+        picked = Quantity(quantity_type=self.qtype.replace_scalar(qt.BoolType()), input_quantities=[self, params_q],
+                          operation=Quantity.pick_samples)
+        picked._volatile = True          # a fresh random draw on every evaluation: never cached on the device
+        return picked
 
     # ---- indexing -------------------------------------------------------------------------------------
     def __getitem__(self, key):

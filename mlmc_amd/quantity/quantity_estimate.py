@@ -7,6 +7,9 @@ out-of-domain mask, the level differences and the sums of quantity_estimate.py:4
 accumulation kernels (mlmc_amd/csrc/moments.hip, cov.hip).  Nothing of shape [M*R, n, 2] or [M*R*R, n, 2] is
 ever materialised.
 """
+import collections
+import os
+
 import numpy as np
 
 from . import quantity as qmod
@@ -77,6 +80,68 @@ def covariance(quantity, moments_fn, cov_at_bottom=True):
     return _CovarianceNode(quantity, moments_fn, cov_at_bottom, qtype)
 
 
+class _DeviceChunkCache:
+    """HBM-resident copies of the raw sample chunks an estimate has consumed (LRU, bounded).
+
+    An MLMC post-processing session runs several passes over the same samples (moments, covariance, level variances,
+    the two passes of construct_density); the first pass uploads each chunk once, later passes -- and later estimates of
+    the same quantity -- read it from HBM, where a whole multi-level estimate is one kernel launch.  288 GB of HBM3E
+    hold 1.8e10 sample pairs; the default budget is MLMC_HIP_DEVICE_CACHE_GB = 64.
+    Keyed by (source quantity, level, chunk id, chunk slice, samples collected on the level): storages are append-only,
+    so a level that has grown misses and is uploaded again.  `device_cache_clear()` drops everything."""
+
+    def __init__(self):
+        self._items = collections.OrderedDict()
+        self._bytes = 0
+        self.uploads = 0
+        self.hits = 0
+
+    @staticmethod
+    def budget():
+        return int(float(os.environ.get("MLMC_HIP_DEVICE_CACHE_GB", "64")) * 2 ** 30)
+
+    def get(self, key):
+        item = self._items.get(key)
+        if item is not None:
+            self._items.move_to_end(key)
+            self.hits += 1
+        return item
+
+    def put(self, key, fine, coarse, owner=None):
+        import torch
+        nbytes = fine.nbytes + (0 if coarse is None else coarse.nbytes)
+        if nbytes > self.budget():
+            return None
+        while self._bytes + nbytes > self.budget() and self._items:
+            _, (_, _, old, _) = self._items.popitem(last=False)
+            self._bytes -= old
+        dev = torch.device("cuda", _lib_device())
+        # `owner` (the source quantity) is kept alive with the entry, so its id() in the key cannot be re-used
+        item = (torch.from_numpy(fine).to(dev), None if coarse is None else torch.from_numpy(coarse).to(dev), nbytes, owner)
+        self._items[key] = item
+        self._bytes += nbytes
+        self.uploads += 1
+        return item
+
+    def clear(self):
+        self._items.clear()
+        self._bytes = 0
+
+
+def _lib_device():
+    from .. import _lib
+    _lib.lib()
+    return _lib._bound_device
+
+
+_device_cache = _DeviceChunkCache()
+
+
+def device_cache_clear():
+    """Drop the HBM-resident sample chunks (call after modifying stored samples in place)."""
+    _device_cache.clear()
+
+
 def _split_fine_coarse(chunk, level_id):
     """[M, n, 2|1] -> contiguous fine[M, n], coarse[M, n] | None (level 0 carries no coarse samples)."""
     fine = np.ascontiguousarray(chunk[:, :, 0], dtype=np.float64)
@@ -109,15 +174,33 @@ def estimate_mean(quantity, group=None):
 
     acc = None
     n_comp = None
+    use_cache = _DeviceChunkCache.budget() > 0 and not getattr(source, "_volatile", False)
+    try:
+        n_collected = tuple(storage_q.n_collected())
+    except Exception:
+        n_collected = None
+        use_cache = False
     for chunk_spec in storage_q.chunks():
-        raw = source.samples(chunk_spec)                         # [M, n, 2|1]
+        sl = chunk_spec.chunk_slice
+        key = (id(source), chunk_spec.level_id, chunk_spec.chunk_id, None if sl is None else (sl.start, sl.stop),
+               None if n_collected is None else n_collected[int(chunk_spec.level_id)])
+        item = _device_cache.get(key) if use_cache else None
+        if item is None:
+            raw = source.samples(chunk_spec)                     # [M, n, 2|1]
+            if raw.shape[1] == 0:
+                if acc is None:
+                    n_comp = raw.shape[0]
+                    acc = engine.LevelAccumulator(fn, n_levels, mode, n_comp=n_comp)
+                continue
+            fine, coarse = _split_fine_coarse(raw, chunk_spec.level_id)
+            item = _device_cache.put(key, fine, coarse, owner=source) if use_cache else None
+            if item is None:
+                item = (fine, coarse, 0, None)                    # not cached: staged through the C ABI
+        fine, coarse = item[0], item[1]
         if acc is None:
-            n_comp = raw.shape[0]
+            n_comp = fine.shape[0]
             assert n_comp * rows_per_comp == quantity_vec_size
             acc = engine.LevelAccumulator(fn, n_levels, mode, n_comp=n_comp)
-        if raw.shape[1] == 0:
-            continue
-        fine, coarse = _split_fine_coarse(raw, chunk_spec.level_id)
         if n_comp == 1:
             fine, coarse = fine[0], (None if coarse is None else coarse[0])
         acc.push(chunk_spec.level_id, fine, coarse)

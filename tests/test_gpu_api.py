@@ -328,3 +328,39 @@ def test_covariance_layouts_of_vector_quantity(hip):
         assert np.array_equal(r.n_samples, ref.n_samples) and np.array_equal(r.n_rm_samples, ref.n_rm_samples)
         assert r.mean.size == ref.mean.size == 4 * 25
         assert close(r.mean.ravel(), ref.mean, 1.0, TOL) and close(r.var.ravel(), ref.var, None, TOL)
+
+
+def test_device_chunk_cache(hip):
+    """Repeated estimates of the same quantity read the samples from HBM; appended samples and sub-sampled quantities
+    bypass the cache."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    steps = [0.5, 0.07, 0.01]
+    levels = level_arrays([3000, 2000, 1000], steps, 1, 0)
+    st = _storage(levels, steps, _scalar_spec(), chunk_size=1024)
+    q = make_root_quantity(st, _scalar_spec())['q'][1]['0'][0, 0]
+    est = Estimate(q, st, Legendre(9, dom))
+    qe.device_cache_clear()
+    cache = qe._device_cache
+    u0, h0 = cache.uploads, cache.hits
+    m1, v1 = est.estimate_moments()
+    n_chunks = 3 + 2 + 1
+    assert cache.uploads - u0 == n_chunks and cache.hits == h0
+    m2, v2 = est.estimate_moments()
+    cov, _ = est.estimate_covariance()
+    assert cache.uploads - u0 == n_chunks and cache.hits - h0 == 2 * n_chunks
+    assert np.array_equal(m1, m2) and np.array_equal(v1, v2) and np.allclose(cov[:, 0], m1, atol=1e-12)
+    # appended samples change n_collected -> the grown level is uploaded again, results follow the storage
+    f, c = levels[2]
+    st.set_level_samples(2, f[0, :10], c[0, :10])
+    m3, _ = est.estimate_moments()
+    assert cache.uploads - u0 == n_chunks + 1 and not np.array_equal(m3, m2)
+    # volatile (sub-sampled) quantities are never cached
+    u1 = cache.uploads
+    sub = q.subsample([300, 200, 100])
+    qe.estimate_mean(qe.moments(sub, Legendre(9, dom)))
+    assert cache.uploads == u1
+    qe.device_cache_clear()
