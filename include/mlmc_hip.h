@@ -103,8 +103,9 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
  * all-reduce (RCCL) then carries everything a multi-GPU estimate has to exchange.  With MLMC_DEVICE the call is
  * asynchronous (stream-ordered); with MLMC_HOST it synchronises. */
 int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind);
-/* HIP-event time (ms) and launch count of the dominant accumulation kernel since create/reset
- * (needs mlmc_init flag bit0); also the algorithmic HBM bytes those launches had to read. */
+/* HIP-event time (ms) and launch count of the dominant accumulation kernel since create or since the previous
+ * call of this function (it returns the totals and clears them; mlmc_accum_reset leaves them alone; needs
+ * mlmc_init flag bit0); also the algorithmic HBM bytes those launches had to read.  Waits for the last launch. */
 int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes);
 
 /* ---- maximum-entropy density (mlmc/tool/simple_distribution.py:9-327) ------------------ */

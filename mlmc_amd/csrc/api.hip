@@ -4,6 +4,7 @@
 #include <new>
 
 #include "common.hpp"
+#include <algorithm>
 
 namespace mlmc {
 
@@ -33,8 +34,13 @@ int ensure(void **p, size_t *cap, size_t bytes) {
     return 0;
 }
 
+static int timing_collect(mlmc_accum *a);
 int timing_begin(mlmc_accum *a) {
     if (!(rt().flags & 1)) return 0;
+    if (a->ev_used >= 8192) {   // bound the pool: fold the finished pairs into the totals
+        MLMC_HIP_CHECK(hipEventSynchronize(a->ev[a->ev_used - 1]));
+        if (int rc = timing_collect(a)) return rc;
+    }
     if (a->ev_used + 2 > a->ev.size()) {
         hipEvent_t e0, e1;
         MLMC_HIP_CHECK(hipEventCreate(&e0));
@@ -241,6 +247,16 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->d_totals = (double *)a->d_state;
     a->d_counts = (int64_t *)(a->d_totals + tot);
     a->d_ticket = (unsigned *)(a->d_counts + 2 * (size_t)n_levels);
+    a->level_flushed.assign(n_levels, 0);
+    if (mode == MLMC_MODE_MOMENTS && n_comp == 1 && b->out_size == 0) {
+        void *dev_view = nullptr;
+        if (hipHostGetDevicePointer(&dev_view, a->h_out, 0) == hipSuccess && dev_view) {
+            a->host_outputs = true;
+            a->h_out_n = (int64_t *)dev_view;
+            a->h_out_s = (double *)(a->h_out_n + 2 * (size_t)n_levels) + 2 * (size_t)n_levels;
+            a->h_out_sp = a->h_out_s + (size_t)n_levels * a->K;
+        }
+    }
     a->d_out_n = (int64_t *)a->d_out;
     a->d_out_nd = (double *)(a->d_out_n + 2 * (size_t)n_levels);
     a->d_out_s = a->d_out_nd + 2 * (size_t)n_levels;
@@ -254,11 +270,8 @@ int mlmc_accum_reset(mlmc_accum *a) {
     if (!a) return fail("mlmc_accum_reset: null argument");
     hipStream_t st = rt().stream;
     a->pending.clear();
+    std::fill(a->level_flushed.begin(), a->level_flushed.end(), 0);
     MLMC_HIP_CHECK(hipMemsetAsync(a->d_state, 0, a->state_bytes, st));
-    a->ev_used = 0;
-    a->ms_total = 0;
-    a->launches = 0;
-    a->alg_bytes = 0;
     return 0;
 }
 
@@ -364,10 +377,30 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
     hipStream_t st = rt().stream;
     if (a->mode == MLMC_MODE_MOMENTS)
         if (int rcf = flush_moments(a)) return rcf;
-    int rc = (a->mode == MLMC_MODE_MOMENTS) ? launch_moments_finalize(a) : launch_cov_finalize(a);
-    if (rc) return rc;
     const int L = a->n_levels;
     const size_t nk = (size_t)L * a->K;
+    if (a->host_outputs && mem_kind == MLMC_HOST) {
+        // the grid reductions already wrote the finished rows of every pushed level into the pinned mirror
+        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        const int64_t *hn = (const int64_t *)a->h_out;
+        const double *hs = (const double *)(hn + 2 * (size_t)L) + 2 * (size_t)L;
+        const size_t K = (size_t)a->K;
+        for (int l = 0; l < L; ++l) {
+            if (a->level_flushed[l]) {
+                n[l] = hn[l];
+                n_rm[l] = hn[L + l];
+                std::memcpy(s + l * K, hs + l * K, sizeof(double) * K);
+                std::memcpy(sp + l * K, hs + nk + l * K, sizeof(double) * K);
+            } else {
+                n[l] = n_rm[l] = 0;
+                std::fill(s + l * K, s + (l + 1) * K, 0.0);
+                std::fill(sp + l * K, sp + (l + 1) * K, 0.0);
+            }
+        }
+        return 0;
+    }
+    int rc = (a->mode == MLMC_MODE_MOMENTS) ? launch_moments_finalize(a) : launch_cov_finalize(a);
+    if (rc) return rc;
     if (mem_kind == MLMC_DEVICE) {
         MLMC_HIP_CHECK(hipMemcpyAsync(n, a->d_out_n, sizeof(int64_t) * L, hipMemcpyDeviceToDevice, st));
         MLMC_HIP_CHECK(hipMemcpyAsync(n_rm, a->d_out_n + L, sizeof(int64_t) * L, hipMemcpyDeviceToDevice, st));
@@ -385,7 +418,7 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
         std::memcpy(s, hs, sizeof(double) * nk);
         std::memcpy(sp, hs + nk, sizeof(double) * nk);
     }
-    return timing_collect(a);
+    return 0;
 }
 
 int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind) {
@@ -400,18 +433,21 @@ int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind) {
     MLMC_HIP_CHECK(hipMemcpyAsync(packed, a->d_out_nd, bytes, mem_kind == MLMC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     if (mem_kind == MLMC_DEVICE) return 0;   // stream-ordered: the caller's collective on the same stream needs no host sync
     MLMC_HIP_CHECK(hipStreamSynchronize(st));
-    return timing_collect(a);
+    return 0;
 }
 
 int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes) {
     if (!a) return fail("mlmc_accum_kernel_time: null argument");
-    if (a->ev_used) {   // events of an asynchronous finalize: wait for the last one, then collect
+    if (a->ev_used) {   // the event pairs are read lazily, here: wait for the last one, then add them up
         MLMC_HIP_CHECK(hipEventSynchronize(a->ev[a->ev_used - 1]));
         if (int rc = timing_collect(a)) return rc;
     }
     if (ms) *ms = a->ms_total;
     if (launches) *launches = a->launches;
     if (alg_bytes) *alg_bytes = a->alg_bytes;
+    a->ms_total = 0;
+    a->launches = 0;
+    a->alg_bytes = 0;
     return 0;
 }
 

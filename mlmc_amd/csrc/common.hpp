@@ -83,7 +83,11 @@ struct mlmc_accum {
     double *d_vals_f = nullptr, *d_vals_c = nullptr; size_t vals_cap = 0;   // materialised moment values (COV of TransformedMoments)
     void *d_out = nullptr;        // finalize outputs, one allocation: n[L] | n_rm[L] (int64) | n, n_rm as fp64 [2L] | s[L*K] | sp[L*K]
     size_t out_bytes = 0;
-    void *h_out = nullptr;        // pinned host mirror of d_out
+    void *h_out = nullptr;        // pinned host mirror of d_out (device-mapped)
+    // MOMENTS with a plain basis and one component: k_reduce_partials writes the finished rows straight into h_out
+    bool host_outputs = false;
+    double *h_out_s = nullptr, *h_out_sp = nullptr; int64_t *h_out_n = nullptr;   // device-side addresses of h_out's parts
+    std::vector<char> level_flushed;   // levels whose rows in h_out are current (set by flush_moments, cleared by reset)
     double *d_out_s = nullptr, *d_out_sp = nullptr, *d_out_nd = nullptr; int64_t *d_out_n = nullptr;
     // timing
     std::vector<hipEvent_t> ev;   // pairs (start, stop)

@@ -130,7 +130,11 @@ int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64
 // trip's loads are issued before the current trip's arithmetic.  Per pair and term: mul + fma (fine), mul + fma
 // (coarse), sub, add, fma = 7 fp64 instructions (level 0: 4).
 // ------------------------------------------------------------------------------------------
+#ifdef MLMC_PROF
+__device__ unsigned long long *g_prof;   // tools/dev/prof_moments.hip
+#endif
 constexpr int MAX_SEG = 8;
+constexpr int PRIO_SLICE_BITS = 15;   // 32768 cycles = 14 us at 2.4 GHz, a few trips of the sample loop
 struct Seg {
     const double *fine, *coarse;   // coarse == nullptr: level 0
     const uint8_t *mask;           // optional keep flags (quantities with M > 1 components)
@@ -144,6 +148,12 @@ struct SegTable {
 struct ReduceTarget {
     double *totals;                // [2][int_R] of this segment's (level, component)
     int64_t *counts;               // (kept, removed) of the level; nullptr: do not count
+    // optional finished outputs in host-mapped pinned memory (plain bases, one component): the thread that updates a
+    // total also writes the caller-visible value, so finalize needs neither a finalize kernel nor a D2H copy
+    double *h_s, *h_sp;            // [R] rows of this level in the pinned mirror; nullptr: not used
+    int64_t *h_n;                  // &n[level]; n_rm[level] is h_n[h_n_stride]
+    const double *scale;           // P_i = scale[i] * Q_i
+    int64_t h_n_stride;
 };
 struct ReduceTable {
     ReduceTarget t[MAX_SEG];
@@ -163,7 +173,18 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp,
     if (i0 < n) { f0 = fine[i0]; if (PAIR) c0 = coarse[i0]; if (mask) m0 = mask[i0]; }
     if (i1 < n) { f1 = fine[i1]; if (PAIR) c1 = coarse[i1]; if (mask) m1 = mask[i1]; }
 
+    // Issue-priority time slicing.  The kernel runs two waves per SIMD (VGPR bound) and the SIMD arbiter serves the
+    // older wave first: with equal priorities the first-dispatched wave of each SIMD runs at its single-wave rate,
+    // finishes after ~60 % of the kernel and leaves its neighbour to run alone -- and a lone wave cannot fill the
+    // fp64 pipe (measured 6.1 vs 4.4 cycles per instruction with both).  So the two waves of a SIMD (wave slots of
+    // opposite parity) take turns at the higher priority in slices of 2^PRIO_SLICE_BITS shader cycles read from the
+    // shared clock: both progress at the same average rate and end together (-4 % kernel time at R = 32).
+    const unsigned prio_parity = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1;   // HW_ID.wave_id[0]
+    unsigned long long prio_clock = __builtin_amdgcn_s_memtime();
     while (i0 < n) {
+        if ((((unsigned)(prio_clock >> PRIO_SLICE_BITS)) & 1u) == prio_parity) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
+        prio_clock = __builtin_amdgcn_s_memtime();   // read now, used at the next trip: the latency is hidden
         const bool v1 = i1 < n;
         const double xf0 = f0, xf1 = f1, xc0 = c0, xc1 = c1;
         const uint8_t mm0 = m0, mm1 = m1;
@@ -220,6 +241,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
     for (int k = 1; k < MAX_SEG; ++k)
         if (k < tab.nseg && (int)blockIdx.x >= tab.seg[k].block0) sg = tab.seg[k];
     const int bid = (int)blockIdx.x - sg.block0;
+#ifdef MLMC_PROF
+    const unsigned long long prof_r0 = __builtin_amdgcn_s_memrealtime(), prof_c0 = __builtin_amdgcn_s_memtime();
+#endif
 
     double s[RT], sp[RT];
 #pragma unroll
@@ -230,6 +254,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
     else
         accum_samples<KIND, RT, false, FIRST>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
 
+#ifdef MLMC_PROF
+    const unsigned long long prof_r1 = __builtin_amdgcn_s_memrealtime(), prof_c1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- block partial: the four waves add their lanes' accumulators into one LDS image [value][lane] in a
     // fixed order, then one thread per value sums the 64 lanes (row stride 65: conflict-free both ways) ----
     __shared__ double red[2 * RT][WAVE + 1];
@@ -261,6 +288,13 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
         int v = ldc[0][threadIdx.x] + ldc[1][threadIdx.x] + ldc[2][threadIdx.x] + ldc[3][threadIdx.x];
         pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = v;
     }
+#ifdef MLMC_PROF
+    if ((threadIdx.x & 63) == 0) {   // per wave: start, loop end, block end (100 MHz ticks); shader cycles of the loop; XCC/CU id
+        unsigned long long *p = g_prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 5;
+        p[0] = prof_r0; p[1] = prof_r1; p[2] = __builtin_amdgcn_s_memrealtime(); p[3] = prof_c1 - prof_c0;
+        p[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    }
+#endif
 }
 
 // Grid reduction of one accumulation launch: block k (1024 threads) sums the partial rows of segment k in a fixed
@@ -295,14 +329,28 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restri
 #pragma unroll
             for (int k = 0; k < 16; ++k) v += lds[k][c];
             const int which = col / RT, term = t0 + col % RT;
-            if (term < int_R) tg.totals[(int64_t)which * int_R + term] += v;
+            if (term < int_R) {
+                const double t = tg.totals[(int64_t)which * int_R + term] + v;
+                tg.totals[(int64_t)which * int_R + term] = t;
+                if (tg.h_s) {   // same expressions as k_moments_finalize
+                    const double c = tg.scale[term];
+                    if (which == 0) tg.h_s[term] = c * t;
+                    else tg.h_sp[term] = (c * c) * t;
+                }
+            }
         }
     }
     if (tg.counts && g == 15) {   // exact integer sums on the last wave
         int64_t a = 0, b = 0;
         for (int i = c; i < nblocks; i += 64) { a += pcounts[2 * (int64_t)(row0 + i)]; b += pcounts[2 * (int64_t)(row0 + i) + 1]; }
         for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-        if (c == 0) { tg.counts[0] += a; tg.counts[1] += b; }
+        if (c == 0) {
+            a += tg.counts[0];
+            b += tg.counts[1];
+            tg.counts[0] = a;
+            tg.counts[1] = b;
+            if (tg.h_n) { tg.h_n[0] = a; tg.h_n[tg.h_n_stride] = b; }
+        }
     }
 }
 
@@ -477,8 +525,13 @@ int flush_moments(mlmc_accum *a) {
         const int rt_sel = sparse_spline ? R : pick_rt(bp.kind, n_terms);
         const int width = 2 * rt_sel;
         int per_cu = 4;
-        if (!sparse_spline)
-            if (int rc = accum_dispatch(0, bp, rt_sel, nullptr, 0, 0, nullptr, nullptr, &per_cu)) return rc;
+        if (!sparse_spline) {
+            static int occ_cache[8][65];   // resident blocks per CU of (kind, RT); 0 = not asked yet
+            int &cached = occ_cache[bp.kind & 7][rt_sel];
+            if (cached == 0)
+                if (int rc = accum_dispatch(0, bp, rt_sel, nullptr, 0, 0, nullptr, nullptr, &cached)) return rc;
+            per_cu = cached;
+        }
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 4) per_cu = 4;
         const int resident = rt().n_cu * per_cu;
@@ -510,6 +563,14 @@ int flush_moments(mlmc_accum *a) {
             total += nb;
             rtab.t[k].totals = a->d_totals + ((int64_t)p.level * a->n_comp + p.comp) * a->int_width;
             rtab.t[k].counts = (p.count && t0 == 0) ? a->d_counts + (int64_t)p.level * 2 : nullptr;
+            if (a->host_outputs) {   // plain basis, one component: the reduction writes the finished rows (see ReduceTarget)
+                rtab.t[k].h_s = a->h_out_s + (int64_t)p.level * R;
+                rtab.t[k].h_sp = a->h_out_sp + (int64_t)p.level * R;
+                rtab.t[k].h_n = a->h_out_n + p.level;
+                rtab.t[k].h_n_stride = a->n_levels;
+                rtab.t[k].scale = a->basis->d_scale;
+                a->level_flushed[p.level] = 1;
+            }
             bytes += p.n * (p.coarse ? 16 : 8);
         }
         if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)total * width)) return rc;

@@ -130,7 +130,8 @@ class LevelAccumulator:
         return unpack_partials(allreduce_partials(packed, group), L, K)
 
     def kernel_time(self):
-        """(ms, launches, algorithmic bytes) of the accumulation kernels since create/reset (needs FLAG_TIMING)."""
+        """(ms, launches, algorithmic bytes) of the accumulation kernels since create or the previous call
+        (needs FLAG_TIMING; returns and clears the totals)."""
         ms = C.c_double()
         launches = C.c_int64()
         nbytes = C.c_int64()
@@ -163,16 +164,17 @@ def shard_bounds(n, rank, world_size):
 
 
 def level_stats(n, s, sp):
-    """Per-level mean and variance of the differences (quantity_estimate.py:70-77)."""
-    l_means, l_vars = [], []
+    """Per-level mean and variance of the differences (quantity_estimate.py:70-77): mean_l = s / n,
+    var_l = (sp - s^2 / n) / (n - 1), inf where n <= 1.  n[L] int, s / sp [L, K]."""
+    nf = np.asarray(n, dtype=np.float64)[:, None]
+    s = np.asarray(s)
     with np.errstate(all="ignore"):
-        for nl, sl, spl in zip(n, s, sp):
-            l_means.append(sl / nl)
-            if nl > 1:
-                l_vars.append((spl - (sl ** 2 / nl)) / (nl - 1))
-            else:
-                l_vars.append(np.full(len(sl), np.inf))
-    return np.array(l_means), np.array(l_vars)
+        l_means = s / nf
+        l_vars = (sp - (s ** 2 / nf)) / (nf - 1.0)
+    few = np.asarray(n) <= 1
+    if few.any():
+        l_vars[few] = np.inf
+    return l_means, l_vars
 
 
 def percentiles(values, q_percent):
