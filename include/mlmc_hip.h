@@ -67,6 +67,9 @@ void mlmc_shutdown(void);
 /* Run all later work on the caller's HIP stream (e.g. the stream RCCL collectives are enqueued on), so that
  * mlmc_accum_finalize_packed(..., MLMC_DEVICE) followed by an all-reduce needs no host synchronisation in between. */
 int mlmc_set_stream(void *hip_stream);
+/* Wait until everything the library has enqueued on its stream is done (asynchronous entry points: mlmc_accum_push
+ * with device buffers, mlmc_expr_eval, mlmc_accum_finalize_packed(MLMC_DEVICE)). */
+int mlmc_synchronize(void);
 const char *mlmc_last_error(void);
 int mlmc_abi_version(void);
 /* name[<=256], CU count, wavefront size, total HBM bytes of the bound device */
@@ -149,6 +152,47 @@ int mlmc_density_integrate(const mlmc_basis *b, const double *lambda, const doub
  * a radix select on the device + NumPy's interpolation formula.  n_valid (may be NULL) = number of non-NaN values. */
 int mlmc_percentiles(const double *x, int64_t n, const double *q_percent, int32_t nq, double *out, int64_t *n_valid,
                      int mem_kind);
+
+/* ---- quantity expressions (mlmc/quantity/quantity.py:35-512: arithmetic, NumPy ufuncs, comparisons, select) ------
+ * A lazily built Quantity tree over one storage is lowered by the host into a straight-line register program that a
+ * per-sample byte-code kernel evaluates in ONE pass over the stored rows: every node of the tree is fused, nothing but
+ * the result rows is written.  A register holds the fine and the coarse value of one row of one sample.
+ * Comparisons follow Quantity._process_mask (:250-262): the result is one flag per sample, true only if the condition
+ * holds for the fine AND the coarse value; MLMC_X_SELECT marks the flags that `Quantity.select` (:137-164) applies. */
+enum {
+    MLMC_X_LOAD = 0,   /* dst = stored row a                       */
+    MLMC_X_CONST,      /* dst = imm                                */
+    MLMC_X_STORE,      /* result row b = reg a                     */
+    MLMC_X_SELECT,     /* keep the sample only if reg a != 0       */
+    MLMC_X_ADD, MLMC_X_SUB, MLMC_X_MUL, MLMC_X_DIV,
+    MLMC_X_MOD,        /* np.remainder (floored, sign of divisor)  */
+    MLMC_X_POW, MLMC_X_MAXIMUM, MLMC_X_MINIMUM, MLMC_X_FMAX, MLMC_X_FMIN, MLMC_X_ATAN2, MLMC_X_HYPOT, MLMC_X_FMOD,
+    MLMC_X_NEG, MLMC_X_ABS, MLMC_X_SQRT, MLMC_X_SQUARE, MLMC_X_RECIP, MLMC_X_EXP, MLMC_X_EXP2, MLMC_X_EXPM1,
+    MLMC_X_LOG, MLMC_X_LOG2, MLMC_X_LOG10, MLMC_X_LOG1P, MLMC_X_SIN, MLMC_X_COS, MLMC_X_TAN, MLMC_X_ASIN, MLMC_X_ACOS,
+    MLMC_X_ATAN, MLMC_X_SINH, MLMC_X_COSH, MLMC_X_TANH, MLMC_X_FLOOR, MLMC_X_CEIL, MLMC_X_TRUNC, MLMC_X_RINT,
+    MLMC_X_SIGN, MLMC_X_CBRT,
+    MLMC_X_LT, MLMC_X_LE, MLMC_X_GT, MLMC_X_GE, MLMC_X_EQ, MLMC_X_NE,   /* per-sample flag (fine AND coarse), 0.0 / 1.0 */
+    MLMC_X_AND, MLMC_X_OR, MLMC_X_NOT, MLMC_X_XOR,                        /* on flags */
+    MLMC_X_N_OPS
+};
+typedef struct {
+    uint16_t op, dst, a, b;   /* registers < n_regs; LOAD: a = input row; STORE: b = output row */
+    double imm;
+} mlmc_expr_instr;
+#define MLMC_EXPR_MAX_REGS 16
+#define MLMC_EXPR_MAX_INSTR 4096
+typedef struct mlmc_expr mlmc_expr;
+int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_regs, int32_t n_in_rows, int32_t n_out_rows,
+                     mlmc_expr **out);
+void mlmc_expr_destroy(mlmc_expr *e);
+/* Evaluate for n samples.  rows_in: host array of n_in_rows DEVICE pointers; each row is the storage layout of one
+ * stored row of a chunk: interleaved (fine, coarse) pairs [n][2] when has_coarse, else [n] (level 0).
+ * fine_out / coarse_out: device buffers of n_out_rows * n doubles (coarse_out ignored without has_coarse).  Without
+ * MLMC_X_SELECT the result rows are [n_out_rows][n]; with it the selected samples are compacted in order and the rows
+ * are [n_out_rows][*n_selected] contiguous.  n_selected (host) receives the surviving sample count; the call
+ * synchronises only when the program selects. */
+int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coarse, int64_t n, double *fine_out,
+                   double *coarse_out, int64_t *n_selected);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mlmc_init": (C.c_int, [C.c_int, C.c_int]),
     "mlmc_shutdown": (None, []),
     "mlmc_set_stream": (C.c_int, [_vp]),
+    "mlmc_synchronize": (C.c_int, []),
     "mlmc_last_error": (C.c_char_p, []),
     "mlmc_abi_version": (C.c_int, []),
     "mlmc_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _ip]),
@@ -66,6 +67,9 @@ SIGNATURES = {
                                     C.c_int32, _vp, _vp, _vp, C.POINTER(MaxentInfo)]),
     "mlmc_density_eval": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.c_int64, _vp, C.c_int]),
     "mlmc_density_integrate": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, _vp, C.c_int64, C.c_int32, _vp]),
+    "mlmc_expr_create": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "mlmc_expr_destroy": (None, [_vp]),
+    "mlmc_expr_eval": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, _vp, _vp, _ip]),
 }
 
 _lock = threading.Lock()

@@ -115,6 +115,13 @@ int mlmc_set_stream(void *stream) {
     return 0;
 }
 
+int mlmc_synchronize(void) {
+    Runtime &r = rt();
+    if (!r.ready) return fail("mlmc_init has not been called (no HIP device bound)");
+    MLMC_HIP_CHECK(hipStreamSynchronize(r.stream));
+    return 0;
+}
+
 void mlmc_shutdown(void) {
     Runtime &r = rt();
     if (!r.ready) return;

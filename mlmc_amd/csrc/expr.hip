@@ -1,0 +1,375 @@
+// Quantity expressions on the device (include/mlmc_hip.h, "quantity expressions").
+//
+// Reference: mlmc/quantity/quantity.py evaluates a tree of NumPy closures chunk by chunk, one temporary [M, n, 2] array
+// per node (:117-135, arithmetic :166-246, ufuncs :366-400, masks :250-306, select :137-164).  Here the host lowers the
+// tree to a register program (mlmc_amd/quantity/lowering.py) and ONE kernel evaluates it per sample: the stored rows
+// are read once (16 B per pair, one 128-bit load), every node is applied in registers, only the result rows are
+// written.  HBM-bound: algorithmic bytes = 16 B per referenced stored row + 16 B per result row, per sample pair.
+//
+// The register file lives in LDS as [reg][side][thread] (a thread touches only its own column: conflict-free), because
+// registers are indexed by the program.  The program itself is read through uniform (scalar) loads.
+#include "common.hpp"
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace mlmc;
+
+struct mlmc_expr {
+    std::vector<mlmc_expr_instr> prog;
+    int n_regs = 0, n_in = 0, n_out = 0;
+    bool selects = false;
+    mlmc_expr_instr *d_prog = nullptr;
+    const double **d_rows = nullptr;      // device copy of the row pointer table
+    // scratch of selecting programs: uncompacted rows, flags, block offsets
+    double *d_tmp_f = nullptr; size_t tmp_f_cap = 0;
+    double *d_tmp_c = nullptr; size_t tmp_c_cap = 0;
+    uint8_t *d_keep = nullptr; size_t keep_cap = 0;
+    int64_t *d_offsets = nullptr; size_t offsets_cap = 0;
+    int64_t *h_total = nullptr;           // pinned
+};
+
+namespace mlmc {
+
+constexpr int X_THREADS = 256;
+constexpr int COMPACT_CHUNK = 4096;   // samples per block of the compaction kernels
+
+__device__ __forceinline__ double np_remainder(double a, double b) {   // numpy npy_remainder / Python float %
+    double m = fmod(a, b);
+    if (b == 0.0) return m;            // NaN
+    if (m != 0.0) {
+        if ((b < 0.0) != (m < 0.0)) m += b;
+    } else {
+        m = copysign(0.0, b);
+    }
+    return m;
+}
+__device__ __forceinline__ double np_maximum(double a, double b) { return (a >= b || a != a) ? a : b; }
+__device__ __forceinline__ double np_minimum(double a, double b) { return (a <= b || a != a) ? a : b; }
+__device__ __forceinline__ double np_sign(double a) { return a != a ? a : (a > 0.0 ? 1.0 : (a < 0.0 ? -1.0 : 0.0)); }
+
+template <bool PAIR>
+__device__ __forceinline__ void binary(int op, double *d, const double *x, const double *y) {   // d may alias x or y
+    constexpr int S = PAIR ? 2 : 1;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const double a = x[s * X_THREADS], b = y[s * X_THREADS];
+        double r;
+        switch (op) {
+            case MLMC_X_ADD: r = a + b; break;
+            case MLMC_X_SUB: r = a - b; break;
+            case MLMC_X_MUL: r = a * b; break;
+            case MLMC_X_DIV: r = a / b; break;
+            case MLMC_X_MOD: r = np_remainder(a, b); break;
+            case MLMC_X_POW: r = pow(a, b); break;
+            case MLMC_X_MAXIMUM: r = np_maximum(a, b); break;
+            case MLMC_X_MINIMUM: r = np_minimum(a, b); break;
+            case MLMC_X_FMAX: r = fmax(a, b); break;
+            case MLMC_X_FMIN: r = fmin(a, b); break;
+            case MLMC_X_ATAN2: r = atan2(a, b); break;
+            case MLMC_X_HYPOT: r = hypot(a, b); break;
+            case MLMC_X_FMOD: r = fmod(a, b); break;
+            case MLMC_X_AND: r = (a != 0.0 && b != 0.0) ? 1.0 : 0.0; break;
+            case MLMC_X_OR: r = (a != 0.0 || b != 0.0) ? 1.0 : 0.0; break;
+            default: r = ((a != 0.0) != (b != 0.0)) ? 1.0 : 0.0; break;   // XOR
+        }
+        d[s * X_THREADS] = r;
+    }
+}
+
+template <bool PAIR>
+__device__ __forceinline__ void unary(int op, double *d, const double *x) {
+    constexpr int S = PAIR ? 2 : 1;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const double a = x[s * X_THREADS];
+        double r;
+        switch (op) {
+            case MLMC_X_NEG: r = -a; break;
+            case MLMC_X_ABS: r = fabs(a); break;
+            case MLMC_X_SQRT: r = sqrt(a); break;
+            case MLMC_X_SQUARE: r = a * a; break;
+            case MLMC_X_RECIP: r = 1.0 / a; break;
+            case MLMC_X_EXP: r = exp(a); break;
+            case MLMC_X_EXP2: r = exp2(a); break;
+            case MLMC_X_EXPM1: r = expm1(a); break;
+            case MLMC_X_LOG: r = log(a); break;
+            case MLMC_X_LOG2: r = log2(a); break;
+            case MLMC_X_LOG10: r = log10(a); break;
+            case MLMC_X_LOG1P: r = log1p(a); break;
+            case MLMC_X_SIN: r = sin(a); break;
+            case MLMC_X_COS: r = cos(a); break;
+            case MLMC_X_TAN: r = tan(a); break;
+            case MLMC_X_ASIN: r = asin(a); break;
+            case MLMC_X_ACOS: r = acos(a); break;
+            case MLMC_X_ATAN: r = atan(a); break;
+            case MLMC_X_SINH: r = sinh(a); break;
+            case MLMC_X_COSH: r = cosh(a); break;
+            case MLMC_X_TANH: r = tanh(a); break;
+            case MLMC_X_FLOOR: r = floor(a); break;
+            case MLMC_X_CEIL: r = ceil(a); break;
+            case MLMC_X_TRUNC: r = trunc(a); break;
+            case MLMC_X_RINT: r = rint(a); break;
+            case MLMC_X_SIGN: r = np_sign(a); break;
+            case MLMC_X_CBRT: r = cbrt(a); break;
+            default: r = (a == 0.0) ? 1.0 : 0.0; break;   // NOT
+        }
+        d[s * X_THREADS] = r;
+    }
+}
+
+__device__ __forceinline__ bool compare(int op, double a, double b) {
+    switch (op) {
+        case MLMC_X_LT: return a < b;
+        case MLMC_X_LE: return a <= b;
+        case MLMC_X_GT: return a > b;
+        case MLMC_X_GE: return a >= b;
+        case MLMC_X_EQ: return a == b;
+        default: return a != b;
+    }
+}
+
+// One thread = one sample; the program counter is uniform over the grid, so every branch below is a scalar branch.
+constexpr int X_TABLE_ROWS = 64;   // row pointers passed by value in the kernel arguments (no table upload)
+struct RowTable {
+    const double *p[X_TABLE_ROWS];
+};
+
+template <bool PAIR>
+__global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__restrict__ prog, int n_instr, RowTable tab,
+                                                    const double *const *__restrict__ rows, int64_t n, int n_regs,
+                                                    double *__restrict__ out_f, double *__restrict__ out_c,
+                                                    uint8_t *__restrict__ keep_out) {
+    extern __shared__ double regs[];   // [n_regs][2][X_THREADS]
+    const int64_t i = (int64_t)blockIdx.x * X_THREADS + threadIdx.x;
+    const bool active = i < n;
+    double *const mine = regs + threadIdx.x;
+    bool keep = true;
+    for (int pc = 0; pc < n_instr; ++pc) {
+        const mlmc_expr_instr ins = prog[pc];
+        double *const d = mine + (size_t)ins.dst * 2 * X_THREADS;
+        const double *const x = mine + (size_t)ins.a * 2 * X_THREADS;
+        const double *const y = mine + (size_t)ins.b * 2 * X_THREADS;
+        const int op = ins.op;
+        if (op == MLMC_X_LOAD) {
+            const double *__restrict__ row = rows ? rows[ins.a] : tab.p[ins.a];
+            if (PAIR) {
+                double2 v = make_double2(0.0, 0.0);
+                if (active) v = reinterpret_cast<const double2 *>(row)[i];
+                d[0] = v.x;
+                d[X_THREADS] = v.y;
+            } else {
+                d[0] = active ? row[i] : 0.0;
+            }
+        } else if (op == MLMC_X_CONST) {
+            d[0] = ins.imm;
+            if (PAIR) d[X_THREADS] = ins.imm;
+        } else if (op == MLMC_X_STORE) {
+            if (active) {
+                out_f[(int64_t)ins.b * n + i] = x[0];
+                if (PAIR) out_c[(int64_t)ins.b * n + i] = x[X_THREADS];
+            }
+        } else if (op == MLMC_X_SELECT) {
+            keep = keep && (x[0] != 0.0);
+        } else if (op >= MLMC_X_LT && op <= MLMC_X_NE) {
+            bool r = compare(op, x[0], y[0]);
+            if (PAIR) r = compare(op, x[X_THREADS], y[X_THREADS]) && r;
+            const double v = r ? 1.0 : 0.0;
+            d[0] = v;
+            if (PAIR) d[X_THREADS] = v;
+        } else if ((op >= MLMC_X_ADD && op <= MLMC_X_FMOD) || op == MLMC_X_AND || op == MLMC_X_OR || op == MLMC_X_XOR) {
+            binary<PAIR>(op, d, x, y);
+        } else {
+            unary<PAIR>(op, d, x);
+        }
+    }
+    if (keep_out && active) keep_out[i] = keep ? 1 : 0;
+}
+
+// ---- order-preserving compaction of the selected samples --------------------------------------------------------
+__global__ __launch_bounds__(X_THREADS) void k_keep_counts(const uint8_t *__restrict__ keep, int64_t n, int64_t *__restrict__ counts) {
+    __shared__ int wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * COMPACT_CHUNK;
+    int c = 0;
+    for (int k = threadIdx.x; k < COMPACT_CHUNK; k += X_THREADS) {
+        const int64_t i = base + k;
+        c += (i < n && keep[i]) ? 1 : 0;
+    }
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of the block counts in place (one block); offsets[nblk] = total
+__global__ __launch_bounds__(1024) void k_scan_counts(int64_t *__restrict__ counts, int nblk, int64_t *__restrict__ total_out) {
+    __shared__ int64_t part[1024];
+    const int per = (nblk + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(nblk, lo + per);
+    int64_t s = 0;
+    for (int k = lo; k < hi; ++k) s += counts[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int k = 0; k < 1024; ++k) { const int64_t v = part[k]; part[k] = run; run += v; }
+        counts[nblk] = run;
+        *total_out = run;
+    }
+    __syncthreads();
+    int64_t run = part[threadIdx.x];
+    for (int k = lo; k < hi; ++k) { const int64_t v = counts[k]; counts[k] = run; run += v; }
+}
+
+__global__ __launch_bounds__(X_THREADS) void k_compact(const uint8_t *__restrict__ keep, const int64_t *__restrict__ offsets,
+                                                       int nblk, int64_t n, int n_rows, const double *__restrict__ src_f,
+                                                       const double *__restrict__ src_c, double *__restrict__ dst_f,
+                                                       double *__restrict__ dst_c) {
+    __shared__ int wcnt[4];
+    const int64_t n_sel = offsets[nblk];
+    int64_t run = offsets[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * COMPACT_CHUNK;
+    for (int k0 = 0; k0 < COMPACT_CHUNK; k0 += X_THREADS) {
+        const int64_t i = base + k0 + threadIdx.x;
+        const bool kp = i < n && keep[i];
+        const unsigned long long ball = __ballot(kp);
+        if (lane == 0) wcnt[wave] = __popcll(ball);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = wcnt[w]; if (w < wave) before += c; total += c; }
+        if (kp) {
+            const int64_t pos = run + before + __popcll(ball & ((1ull << lane) - 1ull));
+            for (int r = 0; r < n_rows; ++r) {
+                dst_f[(int64_t)r * n_sel + pos] = src_f[(int64_t)r * n + i];
+                if (src_c) dst_c[(int64_t)r * n_sel + pos] = src_c[(int64_t)r * n + i];
+            }
+        }
+        run += total;
+        __syncthreads();
+    }
+}
+
+}  // namespace mlmc
+
+extern "C" {
+
+int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_regs, int32_t n_in_rows, int32_t n_out_rows,
+                     mlmc_expr **out) {
+    if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
+    if (!prog || !out) return fail("mlmc_expr_create: null argument");
+    if (n_instr < 1 || n_instr > MLMC_EXPR_MAX_INSTR) return fail("mlmc_expr_create: program length out of range");
+    if (n_regs < 1 || n_regs > MLMC_EXPR_MAX_REGS) return fail("mlmc_expr_create: register count out of range");
+    if (n_in_rows < 1 || n_out_rows < 1) return fail("mlmc_expr_create: a program needs input and output rows");
+    bool selects = false;
+    std::vector<char> written(n_regs, 0), stored(n_out_rows, 0);
+    for (int k = 0; k < n_instr; ++k) {   // validate: the kernel trusts every index
+        const mlmc_expr_instr &in = prog[k];
+        if (in.op >= MLMC_X_N_OPS) return fail("mlmc_expr_create: unknown opcode");
+        const bool reads_a = in.op != MLMC_X_LOAD && in.op != MLMC_X_CONST;
+        const bool reads_b = (in.op >= MLMC_X_ADD && in.op <= MLMC_X_FMOD) || (in.op >= MLMC_X_LT && in.op <= MLMC_X_NE) ||
+                             in.op == MLMC_X_AND || in.op == MLMC_X_OR || in.op == MLMC_X_XOR;
+        const bool writes = in.op != MLMC_X_STORE && in.op != MLMC_X_SELECT;
+        if (in.op == MLMC_X_LOAD && in.a >= n_in_rows) return fail("mlmc_expr_create: input row out of range");
+        if (reads_a && (in.a >= n_regs || !written[in.a])) return fail("mlmc_expr_create: operand a reads an unset register");
+        if (reads_b && (in.b >= n_regs || !written[in.b])) return fail("mlmc_expr_create: operand b reads an unset register");
+        if (in.op == MLMC_X_STORE) {
+            if (in.b >= n_out_rows) return fail("mlmc_expr_create: output row out of range");
+            stored[in.b] = 1;
+        }
+        if (writes) {
+            if (in.dst >= n_regs) return fail("mlmc_expr_create: destination register out of range");
+            written[in.dst] = 1;
+        }
+        if (in.op == MLMC_X_SELECT) selects = true;
+    }
+    for (int r = 0; r < n_out_rows; ++r)
+        if (!stored[r]) return fail("mlmc_expr_create: an output row is never stored");
+    mlmc_expr *e = new (std::nothrow) mlmc_expr();
+    if (!e) return fail("mlmc_expr_create: out of memory");
+    e->prog.assign(prog, prog + n_instr);
+    e->n_regs = n_regs;
+    e->n_in = n_in_rows;
+    e->n_out = n_out_rows;
+    e->selects = selects;
+    if (hipMalloc(&e->d_prog, sizeof(mlmc_expr_instr) * n_instr) != hipSuccess ||
+        hipMalloc(&e->d_rows, sizeof(double *) * n_in_rows) != hipSuccess ||
+        hipHostMalloc(&e->h_total, sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
+        mlmc_expr_destroy(e);
+        return fail("mlmc_expr_create: device allocation failed");
+    }
+    MLMC_HIP_CHECK(hipMemcpy(e->d_prog, prog, sizeof(mlmc_expr_instr) * n_instr, hipMemcpyHostToDevice));
+    *out = e;
+    return 0;
+}
+
+void mlmc_expr_destroy(mlmc_expr *e) {
+    if (!e) return;
+    if (rt().ready) (void)hipStreamSynchronize(rt().stream);
+    void *ptrs[] = {e->d_prog, (void *)e->d_rows, e->d_tmp_f, e->d_tmp_c, e->d_keep, e->d_offsets};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->h_total) (void)hipHostFree(e->h_total);
+    delete e;
+}
+
+int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coarse, int64_t n, double *fine_out,
+                   double *coarse_out, int64_t *n_selected) {
+    if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
+    if (!e || !rows_in || !fine_out) return fail("mlmc_expr_eval: null argument");
+    if (has_coarse && !coarse_out) return fail("mlmc_expr_eval: coarse_out is NULL");
+    if (n < 0 || n > ((int64_t)1 << 31)) return fail("mlmc_expr_eval: n out of range, split the chunk");
+    for (int r = 0; r < e->n_in; ++r)
+        if (!rows_in[r]) return fail("mlmc_expr_eval: a stored row pointer is NULL");
+    if (n_selected) *n_selected = n;
+    if (n == 0) return 0;
+    hipStream_t st = rt().stream;
+    RowTable tab;
+    std::memset(&tab, 0, sizeof(tab));
+    const double *const *d_rows = nullptr;
+    if (e->n_in <= X_TABLE_ROWS) {
+        for (int r = 0; r < e->n_in; ++r) tab.p[r] = rows_in[r];
+    } else {
+        // the table of the previous call may still be read by its kernel: drain the stream, then overwrite it
+        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(hipMemcpy((void *)e->d_rows, rows_in, sizeof(double *) * e->n_in, hipMemcpyHostToDevice));
+        d_rows = e->d_rows;
+    }
+    double *tf = fine_out, *tc = coarse_out;
+    uint8_t *keep = nullptr;
+    int nblk = 0;
+    if (e->selects) {
+        const size_t bytes = sizeof(double) * (size_t)e->n_out * (size_t)n;
+        if (int rc = ensure((void **)&e->d_tmp_f, &e->tmp_f_cap, bytes)) return rc;
+        if (has_coarse)
+            if (int rc = ensure((void **)&e->d_tmp_c, &e->tmp_c_cap, bytes)) return rc;
+        if (int rc = ensure((void **)&e->d_keep, &e->keep_cap, (size_t)n)) return rc;
+        nblk = (int)((n + COMPACT_CHUNK - 1) / COMPACT_CHUNK);
+        if (int rc = ensure((void **)&e->d_offsets, &e->offsets_cap, sizeof(int64_t) * ((size_t)nblk + 1))) return rc;
+        tf = e->d_tmp_f;
+        tc = has_coarse ? e->d_tmp_c : nullptr;
+        keep = e->d_keep;
+    }
+    const size_t lds = sizeof(double) * (size_t)e->n_regs * 2 * X_THREADS;
+    const unsigned blocks = (unsigned)((n + X_THREADS - 1) / X_THREADS);
+    if (has_coarse)
+        hipLaunchKernelGGL(k_expr<true>, dim3(blocks), dim3(X_THREADS), lds, st, e->d_prog, (int)e->prog.size(), tab, d_rows, n,
+                           e->n_regs, tf, tc, keep);
+    else
+        hipLaunchKernelGGL(k_expr<false>, dim3(blocks), dim3(X_THREADS), lds, st, e->d_prog, (int)e->prog.size(), tab, d_rows, n,
+                           e->n_regs, tf, tc, keep);
+    MLMC_HIP_CHECK(hipGetLastError());
+    if (!e->selects) return 0;
+    hipLaunchKernelGGL(k_keep_counts, dim3(nblk), dim3(X_THREADS), 0, st, keep, n, e->d_offsets);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, e->d_offsets, nblk, e->h_total);
+    hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(X_THREADS), 0, st, keep, e->d_offsets, nblk, n, e->n_out, tf, tc, fine_out,
+                       has_coarse ? coarse_out : nullptr);
+    MLMC_HIP_CHECK(hipGetLastError());
+    MLMC_HIP_CHECK(hipStreamSynchronize(st));
+    if (n_selected) *n_selected = *e->h_total;
+    return 0;
+}
+
+}  // extern "C"

@@ -45,6 +45,8 @@ class Quantity:
         self._memo = (None, {})
         # a quantity whose chunks are not a pure function of the stored samples (random sub-sampling below it)
         self._volatile = any(getattr(q, "_volatile", False) for q in self._input_quantities)
+        # symbolic description of the node for the device lowering (quantity/lowering.py); None: host evaluation only
+        self._sym = None
 
     # ---- structure ---------------------------------------------------------------------------
     def get_quantity_storage(self):
@@ -116,6 +118,7 @@ class Quantity:
             return x[..., mask, :]
         selected = Quantity(quantity_type=self.qtype, input_quantities=[self, masks], operation=pick)
         selected._selection_id = id(selected)
+        selected._sym = ("select",)
         return selected
 
     def __array_ufunc__(self, ufunc, method, *args, **kwargs):
@@ -157,7 +160,9 @@ class Quantity:
         """A Quantity if any operand depends on samples, otherwise a folded QuantityConst."""
         for q in quantities:
             if not isinstance(q, QuantityConst):
-                return Quantity(q.qtype, operation=operation, input_quantities=quantities)
+                result = Quantity(q.qtype, operation=operation, input_quantities=quantities)
+                result._sym = ("binop", operation)
+                return result
         return QuantityConst(quantities[0].qtype, value=operation(*[q._value for q in quantities]))
 
     def _reduction_op(self, quantities, operation):
@@ -181,8 +186,10 @@ class Quantity:
         if not isinstance(self.qtype.base_qtype(), qt.ScalarType) or not isinstance(other.qtype.base_qtype(), qt.ScalarType):
             raise TypeError("Quantity has base qtype {}. Quantities with base qtype ScalarType are the only ones "
                             "that support comparison".format(self.qtype.base_qtype()))
-        return Quantity(quantity_type=self.qtype.replace_scalar(qt.BoolType()), input_quantities=[self, other],
+        mask = Quantity(quantity_type=self.qtype.replace_scalar(qt.BoolType()), input_quantities=[self, other],
                         operation=lambda x, y: Quantity._process_mask(x, y, op))
+        mask._sym = ("cmp", op)
+        return mask
 
     def __lt__(self, other):
         return self._mask_quantity(other, operator.lt)
@@ -232,6 +239,7 @@ class Quantity:
             p.k, p.n, p.total_n = p._orig_k, p._orig_n, p._orig_total_n
             return p
         params_q._adjust_value = adjust_value
+        params_q._sym = None                       # per-level mutable state, not a constant
         picked = Quantity(quantity_type=self.qtype.replace_scalar(qt.BoolType()), input_quantities=[self, params_q],
                           operation=Quantity.pick_samples)
         picked._volatile = True          # a fresh random draw on every evaluation: never cached on the device
@@ -243,8 +251,10 @@ class Quantity:
         if not isinstance(self.qtype, qt.ArrayType):
             key = slice(start, start + new_qtype.size())
         parent = self.qtype
-        return Quantity(quantity_type=new_qtype, input_quantities=[self],
+        item = Quantity(quantity_type=new_qtype, input_quantities=[self],
                         operation=lambda y: parent._make_getitem_op(y, key=key))
+        item._sym = ("getitem", key)
+        return item
 
     def __getattr__(self, name):
         if name.startswith("__") or name in ("qtype", "_memo"):
@@ -257,7 +267,9 @@ class Quantity:
 
     @staticmethod
     def _concatenate(quantities, qtype, axis=0):
-        return Quantity(qtype, input_quantities=[*quantities], operation=lambda *chunks: np.concatenate(tuple(chunks), axis=axis))
+        joined = Quantity(qtype, input_quantities=[*quantities], operation=lambda *chunks: np.concatenate(tuple(chunks), axis=axis))
+        joined._sym = ("concat", axis)
+        return joined
 
     @staticmethod
     def _get_base_qtype(args_quantities):
@@ -271,8 +283,16 @@ class Quantity:
         def _ufunc_call(*chunks):
             return getattr(ufunc, method)(*chunks, **kwargs)
         quantities = [Quantity.wrap(arg) for arg in args]
-        return Quantity(quantity_type=Quantity._result_qtype(_ufunc_call, quantities), input_quantities=quantities,
-                        operation=_ufunc_call)
+        from . import lowering
+        if lowering.ufunc_is_lowerable(ufunc, method, kwargs):
+            # element-wise: the rows broadcast, no need to evaluate the first stored chunk to learn the result size
+            rows = max(q.size() for q in quantities)
+            qtype = qt.ArrayType(shape=rows, qtype=Quantity._get_base_qtype(quantities))
+        else:
+            qtype = Quantity._result_qtype(_ufunc_call, quantities)
+        result = Quantity(quantity_type=qtype, input_quantities=quantities, operation=_ufunc_call)
+        result._sym = ("ufunc", ufunc, method, dict(kwargs))
+        return result
 
     @staticmethod
     def wrap(value):
@@ -348,6 +368,7 @@ class QuantityConst(Quantity):
         self._selection_id = None
         self._storage = None
         self._memo = (None, {})
+        self._sym = ("const",)
 
     def _process_value(self, value):
         if isinstance(value, (int, float, bool, np.integer, np.floating)):
@@ -436,6 +457,7 @@ class QuantityStorage(Quantity):
         self._operation = None
         self._selection_id = None
         self._memo = (None, {})
+        self._sym = ("leaf",)
 
     def level_ids(self):
         return self._storage.get_level_ids()

@@ -12,6 +12,7 @@ import os
 
 import numpy as np
 
+from . import lowering
 from . import quantity as qmod
 from . import quantity_types as qt
 from .. import engine
@@ -118,9 +119,23 @@ class _DeviceChunkCache:
         dev = torch.device("cuda", _lib_device())
         # `owner` (the source quantity) is kept alive with the entry, so its id() in the key cannot be re-used
         item = (torch.from_numpy(fine).to(dev), None if coarse is None else torch.from_numpy(coarse).to(dev), nbytes, owner)
+        torch.cuda.current_stream(dev).synchronize()    # the library reads them on its own stream
         self._items[key] = item
         self._bytes += nbytes
         self.uploads += 1
+        return item
+
+    def put_tensors(self, key, fine, coarse, owner=None):
+        """Cache tensors that already live on the device (results of a lowered quantity, stored rows)."""
+        nbytes = fine.numel() * 8 + (0 if coarse is None else coarse.numel() * 8)
+        item = (fine, coarse, nbytes, owner)
+        if nbytes > self.budget():
+            return item
+        while self._bytes + nbytes > self.budget() and self._items:
+            _, (_, _, old, _) = self._items.popitem(last=False)
+            self._bytes -= old
+        self._items[key] = item
+        self._bytes += nbytes
         return item
 
     def clear(self):
@@ -150,6 +165,39 @@ def _split_fine_coarse(chunk, level_id):
     return fine, np.ascontiguousarray(chunk[:, :, 1], dtype=np.float64)
 
 
+def _device_tree_enabled():
+    return os.environ.get("MLMC_HIP_DEVICE_TREE", "1") != "0"
+
+
+def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache):
+    """One stored row of one chunk as a device tensor in the storage's own layout: interleaved (fine, coarse) pairs
+    [n, 2], or [n, 1] at level 0.  Uploaded once per (storage, chunk, row) and shared by every quantity that reads it."""
+    import torch
+    key = ("row", id(plan.leaf)) + chunk_key + (stored_row,)
+    item = _device_cache.get(key) if use_cache else None
+    if item is not None:
+        return item[0]
+    raw = plan.leaf.samples(chunk_spec)                           # [M_stored, n, 2|1], memoised for this estimate
+    row = np.ascontiguousarray(raw[stored_row], dtype=np.float64)
+    dev = torch.device("cuda", _lib_device())
+    t = torch.from_numpy(row).to(dev)
+    torch.cuda.current_stream(dev).synchronize()        # the library reads it on its own stream
+    _device_cache.uploads += 1
+    if use_cache:
+        _device_cache.put_tensors(key, t, None, owner=plan.leaf)
+    return t
+
+
+def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache):
+    """Result rows of a lowered quantity for one chunk: fine [M, n'], coarse [M, n'] | None (torch CUDA tensors)."""
+    rows = [_stored_row_on_device(plan, chunk_spec, chunk_key, r, use_cache) for r in plan.in_rows]
+    n, width = rows[0].shape
+    if n == 0:
+        return None
+    fine, coarse, _ = plan.evaluate(rows, has_coarse=(width == 2), n=n)
+    return fine, coarse
+
+
 def estimate_mean(quantity, group=None):
     """MLMC mean estimator (reference: quantity_estimate.py:22-80).
 
@@ -172,6 +220,8 @@ def estimate_mean(quantity, group=None):
     else:
         source, fn, mode, rows_per_comp = quantity, None, engine.LevelAccumulator.MOMENTS, 1
 
+    # a tree of per-sample nodes runs as one device program over the stored rows (quantity/lowering.py)
+    plan = lowering.plan_for(source) if _device_tree_enabled() else None
     acc = None
     n_comp = None
     use_cache = _DeviceChunkCache.budget() > 0 and not getattr(source, "_volatile", False)
@@ -185,6 +235,15 @@ def estimate_mean(quantity, group=None):
         key = (id(source), chunk_spec.level_id, chunk_spec.chunk_id, None if sl is None else (sl.start, sl.stop),
                None if n_collected is None else n_collected[int(chunk_spec.level_id)])
         item = _device_cache.get(key) if use_cache else None
+        if item is None and plan is not None:
+            got = _evaluate_on_device(plan, chunk_spec, key[1:], use_cache)
+            if got is None:
+                if acc is None:
+                    n_comp = plan.n_out
+                    acc = engine.LevelAccumulator(fn, n_levels, mode, n_comp=n_comp)
+                continue
+            item = (_device_cache.put_tensors(key, got[0], got[1], owner=source) if use_cache
+                    else (got[0], got[1], 0, None))
         if item is None:
             raw = source.samples(chunk_spec)                     # [M, n, 2|1]
             if raw.shape[1] == 0:
@@ -197,6 +256,11 @@ def estimate_mean(quantity, group=None):
             if item is None:
                 item = (fine, coarse, 0, None)                    # not cached: staged through the C ABI
         fine, coarse = item[0], item[1]
+        if fine.shape[-1] == 0:                                   # every sample of the chunk was deselected
+            if acc is None:
+                n_comp = fine.shape[0]
+                acc = engine.LevelAccumulator(fn, n_levels, mode, n_comp=n_comp)
+            continue
         if acc is None:
             n_comp = fine.shape[0]
             assert n_comp * rows_per_comp == quantity_vec_size

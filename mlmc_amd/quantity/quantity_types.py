@@ -113,7 +113,9 @@ class TimeSeriesType(QType):
             cuts = np.arange(1, len(times)) * inner.size()
             parts = np.split(y, cuts, axis=-3)
             return interpolate.interp1d(times, parts, axis=0)(value)
-        return qmod.Quantity(quantity_type=inner, input_quantities=[quantity], operation=interp)
+        result = qmod.Quantity(quantity_type=inner, input_quantities=[quantity], operation=interp)
+        result._sym = ("interp", tuple(times), value, inner.size())
+        return result
 
 
 class FieldType(QType):

@@ -364,3 +364,165 @@ def test_device_chunk_cache(hip):
     qe.estimate_mean(qe.moments(sub, Legendre(9, dom)))
     assert cache.uploads == u1
     qe.device_cache_clear()
+
+
+# ---- quantity trees evaluated on the device -----------------------------------------------
+def _tree_env(on):
+    os.environ["MLMC_HIP_DEVICE_TREE"] = "1" if on else "0"
+
+
+@pytest.mark.parametrize("chunk_size", [None, 2000])
+def test_device_tree_chunks_match_the_host_tree(hip, chunk_size):
+    """Every expression of the zoo (tests/test_lowering.py): the byte-code kernel's rows for each stored chunk against the
+    host evaluation of the same tree (mlmc/quantity/quantity.py semantics).  IEEE arithmetic, comparisons, select and
+    row bookkeeping are bit-exact; libm-backed ufuncs (sin, exp, pow, ...) agree to 1e-13 relative."""
+    import torch
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from tests.test_lowering import _spec, expression_zoo, host_chunk, make_storage
+    st = make_storage((3000, 2100, 1100), chunk_size=chunk_size)
+    root = make_root_quantity(st, _spec())
+    dev = torch.device("cuda", 0)
+    exact = {"leaf_scalar", "leaf_rows", "whole_root", "add_const", "radd_rsub", "mul_div", "mod", "rmod_neg", "array_const",
+             "rows_plus_scalar", "central", "ufunc_binary", "ufunc_add", "interp", "interp_edge", "select_gt", "select_two",
+             "select_expr", "select_not", "select_vec_mask", "eq_ne", "shared_subexpr", "qarray"}
+    for name, q in expression_zoo(root).items():
+        plan = lowering.lower(q)
+        for chunk in st.chunks():
+            stored = st.sample_pairs_level(chunk)
+            want = host_chunk(q, chunk)
+            rows = [torch.from_numpy(np.ascontiguousarray(stored[r])).to(dev) for r in plan.in_rows]
+            torch.cuda.synchronize()
+            fine, coarse, _ = plan.evaluate(rows, has_coarse=(stored.shape[-1] == 2), n=stored.shape[1], sync=True)
+            got = fine.cpu().numpy()[:, :, None]
+            if coarse is not None:
+                got = np.concatenate([got, coarse.cpu().numpy()[:, :, None]], axis=2)
+            assert got.shape == want.shape, (name, chunk.level_id, got.shape, want.shape)
+            if name in exact:
+                assert np.array_equal(got, want, equal_nan=True), (name, chunk.level_id, np.nanmax(np.abs(got - want)))
+            else:
+                assert np.allclose(got, want, rtol=1e-13, atol=1e-15, equal_nan=True), (name, np.nanmax(np.abs(got - want)))
+
+
+def test_device_tree_special_values(hip):
+    """np.remainder / maximum / minimum / sign / comparisons with NaN, infinities, zeros of both signs."""
+    import torch
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.sample_storage import Memory
+    from mlmc_amd.quantity.quantity_spec import QuantitySpec
+    spec = [QuantitySpec(name="q", unit="", shape=(2, 1), times=[1], locations=['0'])]
+    vals = np.array([0.0, -0.0, 1.0, -1.0, 2.5, -2.5, 7.0, -7.0, np.inf, -np.inf, np.nan, 1e-300, -1e-300, 3.0, -3.0, 1e300])
+    a, b = np.meshgrid(vals, vals, indexing="ij")
+    fine = np.stack([a.ravel(), b.ravel()], axis=1)                   # [n, 2]
+    st = Memory()
+    st.save_global_data(result_format=spec, level_parameters=[[0.5], [0.1]])
+    st.set_level_samples(0, fine, None)
+    st.set_level_samples(1, fine, fine[::-1].copy())
+    st.save_n_ops([(0, (1.0, 1)), (1, (1.0, 1))])
+    root = make_root_quantity(st, spec)['q'][1]['0']
+    x, y = root[0], root[1]
+    dev = torch.device("cuda", 0)
+    from mlmc_amd.quantity.quantity import Quantity
+    trees = {"mod": x % y, "fmod": np.fmod(x, y), "max": np.maximum(x, y), "min": np.minimum(x, y), "fmax": np.fmax(x, y),
+             "fmin": np.fmin(x, y), "sign": np.sign(x), "div": x / y, "floor": np.floor(x / 3.0), "rint": np.rint(x * 0.5),
+             "sel_lt": Quantity.QArray([x, y]).select(x < y), "sel_ge": Quantity.QArray([x, y]).select(x >= y),
+             "sel_eq": Quantity.QArray([x, y]).select(x == y), "sel_ne": Quantity.QArray([x, y]).select(x != y)}
+    from tests.test_lowering import host_chunk
+    with np.errstate(all="ignore"):
+        for name, q in trees.items():
+            plan = lowering.lower(q)
+            for chunk in st.chunks():
+                stored = st.sample_pairs_level(chunk)
+                want = host_chunk(q, chunk)
+                rows = [torch.from_numpy(np.ascontiguousarray(stored[r])).to(dev) for r in plan.in_rows]
+                torch.cuda.synchronize()
+                f, c, _ = plan.evaluate(rows, has_coarse=(stored.shape[-1] == 2), n=stored.shape[1], sync=True)
+                got = f.cpu().numpy()[:, :, None]
+                if c is not None:
+                    got = np.concatenate([got, c.cpu().numpy()[:, :, None]], axis=2)
+                assert got.shape == want.shape, (name, got.shape, want.shape)
+                same = (got == want) | (np.isnan(got) & np.isnan(want))
+                assert same.all(), (name, chunk.level_id, got[~same][:5], want[~same][:5])
+                if name not in ("max", "min", "fmax", "fmin"):     # max(+0, -0): NumPy's own answer depends on its SIMD path
+                    z = (got == 0) & (want == 0)
+                    assert np.array_equal(np.signbit(got[z]), np.signbit(want[z])), name
+
+
+def test_device_tree_estimates_match_host_tree(hip):
+    """estimate_mean / Estimate over derived quantities: device-evaluated tree vs the host-evaluated tree feeding the
+    same device estimator (MLMC_HIP_DEVICE_TREE=0), and vs the NumPy oracle for one of them."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from tests.test_lowering import _spec, make_storage
+    st = make_storage((6000, 3100, 1700), chunk_size=2500)
+    root = make_root_quantity(st, _spec())
+    x = root['length'][2]['10'][0]
+    y = root['width'][1]['30'][1]
+    dom = (-1.5, 6.0)
+    fn = Legendre(9, dom)
+    trees = {
+        "central": (x - 2.0) * (x - 2.0),
+        "ratio": (x * y) / (np.abs(y) + 1.0),
+        "selected": x.select(x > 1.2, y < 3.5),
+        "vector": root['length'].time_interpolation(1.5)['20'] * np.array([1.0, 0.5]),
+        "transcendental": np.log1p(np.abs(x)) + np.sin(y),
+    }
+    try:
+        for name, q in trees.items():
+            res = {}
+            for on in (False, True):
+                _tree_env(on)
+                qe.device_cache_clear()
+                m = qe.estimate_mean(qe.moments(q, fn))
+                plain = qe.estimate_mean(q)
+                cov = qe.estimate_mean(qe.covariance(q, Legendre(4, dom))) if q.size() == 1 else None
+                res[on] = (m, plain, cov)
+            for a, b in zip(res[False], res[True]):
+                if a is None:
+                    continue
+                assert a.n_samples.tolist() == b.n_samples.tolist() and a.n_rm_samples.tolist() == b.n_rm_samples.tolist(), name
+                sm = np.max(np.abs(a.l_means))
+                assert close(b.l_means, a.l_means, scale=sm) and close(b.mean, a.mean, scale=sm), name
+                assert close(b.l_vars, a.l_vars, scale=np.max(np.abs(a.l_vars))) and close(b.var, a.var, scale=np.max(np.abs(a.var))), name
+            if name == "selected":
+                assert res[True][0].n_samples[1] < 3100                     # the selection really dropped samples
+        # oracle for the central second moment: samples -> (x - 2)^2 on the host, then the NumPy restatement
+        _tree_env(True)
+        qe.device_cache_clear()
+        est = Estimate(trees["central"], st, fn)
+        means, variances = est.estimate_moments()
+        b = onp.Basis(onp.LEGENDRE, 9, dom)
+        per_level = [[], [], []]
+        for chunk in st.chunks():
+            raw = st.sample_pairs_level(chunk)[4:5]
+            per_level[chunk.level_id].append((raw - 2.0) * (raw - 2.0))
+        ref = onp.estimate_mean(per_level, lambda v: onp.moments_rows(b, v))
+        assert close(means, ref.mean, scale=np.max(np.abs(ref.mean))) and close(variances, ref.var, scale=np.max(np.abs(ref.var)))
+    finally:
+        os.environ.pop("MLMC_HIP_DEVICE_TREE", None)
+        qe.device_cache_clear()
+
+
+def test_device_tree_shares_stored_rows_between_quantities(hip):
+    from mlmc_amd import Legendre
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from tests.test_lowering import _spec, make_storage
+    st = make_storage((900, 500, 300))
+    root = make_root_quantity(st, _spec())
+    x = root['length'][2]['10'][0]
+    y = root['width'][1]['30'][1]
+    fn = Legendre(5, (-1.5, 6.0))
+    qe.device_cache_clear()
+    cache = qe._device_cache
+    u0 = cache.uploads
+    qe.estimate_mean(qe.moments(x + 1.0, fn))
+    assert cache.uploads - u0 == 3                       # one stored row, three levels (not 24 rows)
+    qe.estimate_mean(qe.moments(x * x, fn))              # another quantity over the same stored row: no upload
+    assert cache.uploads - u0 == 3
+    qe.estimate_mean(qe.moments(x * y, fn))              # one more stored row
+    assert cache.uploads - u0 == 6
+    qe.device_cache_clear()

@@ -1,0 +1,151 @@
+"""Device lowering of Quantity trees (mlmc_amd/quantity/lowering.py): the program of every lowerable tree, run by a
+NumPy interpreter, must reproduce the host evaluation of the tree (which mirrors mlmc/quantity/quantity.py and is
+covered against the reference's behaviour in test_host_logic.py).  No GPU needed.  The same expression zoo is run on
+the device in tests/test_gpu_api.py::test_device_tree_*."""
+import numpy as np
+import pytest
+
+
+def _spec():
+    from mlmc_amd.quantity.quantity_spec import QuantitySpec
+    return [QuantitySpec(name="length", unit="m", shape=(2, 1), times=[1, 2, 3], locations=['10', '20']),
+            QuantitySpec(name="width", unit="mm", shape=(2, 1), times=[1, 2, 3], locations=['30', '40'])]
+
+
+def make_storage(n=(700, 500, 300), chunk_size=None, seed=5):
+    from mlmc_amd.sample_storage import Memory
+    rng = np.random.default_rng(seed)
+    st = Memory(chunk_size=chunk_size)
+    st.save_global_data(result_format=_spec(), level_parameters=[[0.5], [0.1], [0.02]])
+    M = 24
+    for l, nl in enumerate(n):
+        fine = rng.normal(size=(nl, M)) + 2.0
+        coarse = fine + 0.1 * rng.normal(size=(nl, M)) if l else None
+        st.set_level_samples(l, fine, coarse)
+    st.save_n_ops([(l, (10.0 * (l + 1) * nl, nl)) for l, nl in enumerate(n)])
+    return st
+
+
+def expression_zoo(root):
+    """name -> quantity; the kinds of trees the reference's test/test_quantity_concept.py builds."""
+    length = root['length']
+    width = root['width']
+    loc = length[2]['10']                       # 2 rows
+    x = loc[0]
+    y = width[1]['30'][1]
+    zoo = {
+        "leaf_scalar": x,
+        "leaf_rows": length[3],                 # 4 rows (two locations)
+        "whole_root": root,                     # all 24 rows
+        "add_const": x + 1.5,
+        "radd_rsub": 3.0 - (2.0 + x),
+        "mul_div": (x * y) / (y + 10.0),
+        "mod": (x * 7.0) % 3.0,
+        "rmod_neg": (-5.0) % (x + 4.0),
+        "array_const": loc * np.array([2.0, -1.0]),
+        "rows_plus_scalar": length[1] + x,      # 4 rows broadcast with 1
+        "central": (x - 2.0) * (x - 2.0),
+        "ufunc_sin_exp": np.sin(x) + np.exp(np.negative(y)),
+        "ufunc_binary": np.maximum(x, y) - np.minimum(x, 2.0),
+        "ufunc_pow_sqrt": np.sqrt(np.abs(x)) + np.power(np.abs(y), 1.5),
+        "ufunc_add": np.add(x, y),
+        "interp": length.time_interpolation(2.5)['20'],
+        "interp_edge": width.time_interpolation(1.0),
+        "select_gt": x.select(x > 2.0),
+        "select_two": loc.select(loc < 4.5, y >= 1.0),
+        "select_expr": (x * y).select(np.logical_or(x > 2.5, y < 1.5)),
+        "select_not": x.select(np.logical_not(x > 2.0)),
+        "select_vec_mask": loc.select(loc > 0.5),                      # all rows must pass
+        "eq_ne": x.select(x != y, y == y),
+        "deep": np.log1p(np.abs(np.tanh(x) * np.cos(y) + np.sqrt(np.square(y) + 1.0))) / (1.0 + np.exp2(np.negative(x))),
+        "shared_subexpr": (x + y) * (x + y) + (x + y),
+    }
+    from mlmc_amd.quantity.quantity import Quantity
+    zoo["qarray"] = Quantity.QArray([x, y, x + y])
+    return zoo
+
+
+def host_chunk(q, chunk):
+    from mlmc_amd.quantity import quantity as qmod
+    qmod.cache_clear()
+    return np.asarray(q.samples(chunk), dtype=np.float64)
+
+
+def test_programs_reproduce_the_host_tree():
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    st = make_storage()
+    root = make_root_quantity(st, _spec())
+    zoo = expression_zoo(root)
+    chunks = list(st.chunks())
+    for name, q in zoo.items():
+        plan = lowering.lower(q)
+        assert plan.n_regs <= lowering.MAX_REGS and plan.n_out == q.size(), name
+        for chunk in chunks:
+            stored = st.sample_pairs_level(chunk)
+            want = host_chunk(q, chunk)
+            got, keep = lowering.run_reference(plan, stored)
+            assert got.shape == want.shape, (name, got.shape, want.shape)
+            # same IEEE operations in the same order; libm-backed ufuncs are the same NumPy calls here
+            assert np.array_equal(got, want, equal_nan=True), (name, np.nanmax(np.abs(got - want)))
+        assert plan.selects == name.startswith(("select", "eq_ne")), name
+
+
+def test_programs_read_only_the_rows_they_need_and_share_subexpressions():
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    st = make_storage((50, 40, 30))
+    root = make_root_quantity(st, _spec())
+    x = root['length'][2]['10'][0]
+    y = root['width'][1]['30'][1]
+    plan = lowering.lower(x)
+    assert plan.in_rows == [4] and len(plan.prog) == 2 and plan.n_regs == 1          # LOAD, STORE
+    plan = lowering.lower((x + y) * (x + y) + (x + y))
+    names = [lowering._OP_NAMES[p[0]] for p in plan.prog]
+    assert sorted(plan.in_rows) == [4, 12 + 1] and names.count("ADD") == 2 and names.count("LOAD") == 2
+    plan = lowering.lower(root * 2.0)                    # 24 independent rows: stored one by one, few registers
+    assert plan.n_out == 24 and plan.n_regs <= 3
+    # the instruction array matches the C struct of include/mlmc_hip.h
+    import ctypes as C
+    assert C.sizeof(lowering.ExprInstr) == 16
+    arr = plan.instr_array()
+    assert arr[0].op == lowering.OP["LOAD"] or arr[0].op == lowering.OP["CONST"]
+
+
+def test_trees_that_are_not_per_sample_functions_fall_back():
+    from mlmc_amd.quantity import lowering, quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd import Legendre
+    st = make_storage((50, 40, 30))
+    root = make_root_quantity(st, _spec())
+    x = root['length'][2]['10'][0]
+    assert lowering.plan_for(x.subsample([10, 10, 10])) is None                      # random draw
+    assert lowering.plan_for(x.subsample([10, 10, 10]) + 1.0) is None
+    assert lowering.plan_for(np.add.reduce(root['length'][2]['10'], axis=0)) is None  # ufunc method other than __call__
+    assert lowering.plan_for(qe.moment(x, Legendre(3, (0.0, 4.0)), 1)) is None        # user closure
+    with pytest.raises(lowering.NotLowerable):
+        lowering.lower(root['length'].time_interpolation(7.0))                         # outside the stored times
+    with pytest.raises(lowering.NotLowerable):
+        lowering.lower(x > 1.0)                                                        # a mask has no sample rows
+    # too many live values for the register file: 20 distinct terms all needed by the last row
+    terms = [np.sin(x + float(k)) for k in range(20)]
+    prod = terms[0]
+    for t in terms[1:]:
+        prod = prod * t
+    assert lowering.plan_for(prod) is not None           # a chain: each term dies at once
+    from mlmc_amd.quantity.quantity import Quantity
+    rev = Quantity.QArray(terms + [terms[k] + terms[19 - k] for k in range(20)])
+    assert lowering.plan_for(rev) is not None or True    # may or may not fit; must not raise
+
+
+def test_header_opcodes_match_the_python_table():
+    import os
+    import re
+    from mlmc_amd.quantity import lowering
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mlmc_hip.h")).read()
+    body = hdr[hdr.index("MLMC_X_LOAD = 0"):hdr.index("MLMC_X_N_OPS")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"MLMC_X_([A-Z0-9]+)", body)
+    assert names == lowering._OP_NAMES
+    assert int(re.search(r"MLMC_EXPR_MAX_REGS (\d+)", hdr).group(1)) == lowering.MAX_REGS
+    assert int(re.search(r"MLMC_EXPR_MAX_INSTR (\d+)", hdr).group(1)) == lowering.MAX_INSTR
