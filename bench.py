@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: moment-evals/s of one complete MLMC moment estimate on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|5|6]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
 (one rank per GPU, RCCL).  Workload at N = 1: BASELINE.json configs[1] -- 3 levels x 10^7 synthetic samples,
@@ -35,6 +35,9 @@ CONFIGS = {
     5: dict(L=1, n_per_level=12_500_000, R=128, mode="moments", basis="Spline",
             workload="BASELINE configs[4] per-GPU share: 1 level x 1.25e7 synthetic samples per GPU (1e8 over 8 GPUs), Spline "
                      "n_moments=128 (cubic B-spline moments, not part of the reference), mean+var estimate + max-entropy PDF"),
+    6: dict(L=3, n_per_level=10_000_000, R=32, mode="tree",
+            workload="SURVEY 8(f) row 1: derived quantity (x - 0.1)^2 / (|y| + 1) of two stored rows, evaluated by the byte-code "
+                     "kernel (3 levels x 1e7 samples per GPU), then the Legendre n_moments=32 mean+var estimate"),
 }
 
 
@@ -97,6 +100,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     cfg = CONFIGS[args.config]
     L, n_l, R = cfg["L"], cfg["n_per_level"], cfg["R"]
+    if cfg["mode"] == "tree":
+        out = tree_bench(args, cfg, world, rank, dev, dist)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     dom = (-3.7190164854556804, 3.7190164854556804)   # scipy.stats.norm().ppf([1e-4, 1 - 1e-4]) (test/test_run.py:71)
     steps = [s[0] for s in onp.determine_level_parameters(L, [0.5, 0.01])] if L > 1 else [0.01]
     fn = Spline(R, dom) if cfg.get("basis") == "Spline" else Legendre(R, dom)
@@ -223,6 +235,125 @@ def main():
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def tree_bench(args, cfg, world, rank, dev, dist):
+    """--config 6: a Quantity tree over two stored rows, lowered to a register program and evaluated by k_expr
+    (mlmc_amd/csrc/expr.hip), feeding the moments estimate.  Step = evaluation of every level's chunk + one estimate."""
+    import gc
+    import torch
+    from mlmc_amd import Legendre
+    from mlmc_amd.engine import LevelAccumulator, level_stats
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.quantity.quantity_spec import QuantitySpec
+    from mlmc_amd.sample_storage import Memory
+    from oracle import oracle_np as onp
+    L, n_l, R = cfg["L"], cfg["n_per_level"], cfg["R"]
+    steps = [s[0] for s in onp.determine_level_parameters(L, [0.5, 0.01])]
+    # the tree, built through the reference-style API over a (tiny) storage with the same two stored rows
+    spec = [QuantitySpec(name="q", unit="", shape=(2, 1), times=[1], locations=['0'])]
+    st = Memory()
+    st.save_global_data(result_format=spec, level_parameters=[[h] for h in steps])
+    for l in range(L):
+        st.set_level_samples(l, np.ones((2, 2)), np.ones((2, 2)) if l else None)
+    root = make_root_quantity(st, spec)['q'][1]['0']
+    x, y = root[0], root[1]
+    q = (x - 0.1) * (x - 0.1) / (np.abs(y) + 1.0)
+    plan = lowering.lower(q)
+    dom = (0.0, 12.0)
+    fn = Legendre(R, dom)
+    acc = LevelAccumulator(fn, L, LevelAccumulator.MOMENTS)
+    # stored rows in the storage layout: interleaved (fine, coarse) pairs [n, 2]; level 0: [n, 1]
+    stored = []
+    for l in range(L):
+        rows = []
+        for r in range(2):
+            f, c = synth_device(l, n_l, steps, 1234 + 1000 * rank + 77 * r, dev)
+            rows.append(f.reshape(-1, 1).contiguous() if c is None else torch.stack([f, c], dim=1).contiguous())
+        stored.append(rows)
+    torch.cuda.synchronize()
+
+    def one_step():
+        acc.reset()
+        keep = []
+        for l in range(L):
+            f, c, _ = plan.evaluate(stored[l], has_coarse=(l > 0), n=n_l)
+            keep.append((f, c))
+            acc.push(l, f[0], None if c is None else c[0])
+        n, n_rm, s, sp = acc.finalize()
+        l_means, l_vars = level_stats(n, s, sp)
+        with np.errstate(all="ignore"):
+            return n, n_rm, np.sum(l_means, axis=0), np.sum(l_vars / n[:, None], axis=0)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    gc.collect()
+    gc.disable()
+    plan.kernel_time()
+    acc.kernel_time()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n, n_rm, mean, var = one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    x_ms, x_launches, x_bytes = plan.kernel_time()
+    a_ms, a_launches, _ = acc.kernel_time()
+    gbs = (x_bytes / 1e9) / (x_ms / 1e3) if x_ms > 0 else 0.0
+    out = {
+        "metric": "moment-evals/sec (samples x n_moments)", "value": world * L * n_l * R * args.steps / elapsed,
+        "unit": "moment-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": cfg["workload"], "levels": L, "samples_per_level_per_gpu": n_l, "n_moments": R,
+                   "tree": "(x - 0.1) * (x - 0.1) / (np.abs(y) + 1.0)", "program_instructions": len(plan.prog),
+                   "program_registers": plan.n_regs, "stored_rows_read": len(plan.in_rows), "result_rows": plan.n_out},
+        "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_expr",
+                     "avg_launch_ms": round(x_ms / max(x_launches, 1), 5),
+                     "alg_bytes_per_launch": int(x_bytes / max(x_launches, 1)), "launches_per_step": x_launches // max(args.steps, 1),
+                     "moments_kernel_ms_per_step": round(a_ms / max(args.steps, 1), 5)},
+        "result_check": {"mean0": float(mean[0]), "var0": float(var[0]), "n_removed": [int(v) for v in n_rm]},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU leg: the same tree evaluated the way the reference does it (NumPy closures over [M, n, 2] chunks,
+        # mlmc/quantity/quantity.py) on a bounded sample, and the parity of the device rows against it
+        from mlmc_amd.quantity.quantity_spec import ChunkSpec
+        m = 2_000_000
+        host_rows = np.stack([stored[1][0][:m].cpu().numpy(), stored[1][1][:m].cpu().numpy()])     # [2, m, 2]
+        st2 = Memory()
+        st2.save_global_data(result_format=spec, level_parameters=[[h] for h in steps])
+        st2.set_level_samples(0, host_rows[:, :4, 0].T.copy(), None)
+        st2.set_level_samples(1, host_rows[:, :, 0].T.copy(), host_rows[:, :, 1].T.copy())
+        root2 = make_root_quantity(st2, spec)['q'][1]['0']
+        q2 = (root2[0] - 0.1) * (root2[0] - 0.1) / (np.abs(root2[1]) + 1.0)
+        chunk = [c for c in st2.chunks() if c.level_id == 1][0]
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            from mlmc_amd.quantity import quantity as qmod
+            qmod.cache_clear()
+            want = q2.samples(chunk)
+        dt = (time.perf_counter() - t0) / reps
+        f, c, _ = plan.evaluate([stored[1][0][:m].contiguous(), stored[1][1][:m].contiguous()], True, m, sync=True)
+        got = np.stack([f.cpu().numpy(), c.cpu().numpy()], axis=2)
+        out["cpu_baseline"] = {"value": m / dt, "unit": "samples/s (tree evaluation only)", "cores": 1, "kind": "port",
+                               "sample": "NumPy evaluation of the same tree on one level-1 chunk of 2e6 sample pairs (reference "
+                                         "algorithm: one temporary per node)", "gpu_samples_per_s": n_l * x_launches / (x_ms / 1e3) if x_ms else None}
+        out["parity"] = {"rows_bit_exact": bool(np.array_equal(got, want)), "max_abs_err": float(np.max(np.abs(got - want))),
+                         "ok": bool(np.array_equal(got, want))}
+    return out
 
 
 def pdf_solve_timing(fn, L, data, LevelAccumulator, level_stats):

@@ -193,6 +193,9 @@ void mlmc_expr_destroy(mlmc_expr *e);
  * synchronises only when the program selects. */
 int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coarse, int64_t n, double *fine_out,
                    double *coarse_out, int64_t *n_selected);
+/* HIP-event time (ms), launches and algorithmic bytes (8 B per value of every referenced stored row and every result
+ * row) of the evaluation kernel since create or the previous call; same contract as mlmc_accum_kernel_time. */
+int mlmc_expr_kernel_time(mlmc_expr *e, double *ms, int64_t *launches, int64_t *alg_bytes);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mlmc_expr_create": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "mlmc_expr_destroy": (None, [_vp]),
     "mlmc_expr_eval": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, _vp, _vp, _ip]),
+    "mlmc_expr_kernel_time": (C.c_int, [_vp, _dp, _ip, _ip]),
 }
 
 _lock = threading.Lock()

@@ -10,6 +10,7 @@
 // registers are indexed by the program.  The program itself is read through uniform (scalar) loads.
 #include "common.hpp"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -20,6 +21,7 @@ struct mlmc_expr {
     std::vector<mlmc_expr_instr> prog;
     int n_regs = 0, n_in = 0, n_out = 0;
     bool selects = false;
+    bool heavy = false;                   // uses a libm-backed operation (k_expr<.., HEAVY = true>)
     mlmc_expr_instr *d_prog = nullptr;
     const double **d_rows = nullptr;      // device copy of the row pointer table
     // scratch of selecting programs: uncompacted rows, flags, block offsets
@@ -28,7 +30,22 @@ struct mlmc_expr {
     uint8_t *d_keep = nullptr; size_t keep_cap = 0;
     int64_t *d_offsets = nullptr; size_t offsets_cap = 0;
     int64_t *h_total = nullptr;           // pinned
+    // HIP-event timing of k_expr (mlmc_init flag bit0), read lazily by mlmc_expr_kernel_time
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double ms_total = 0;
+    int64_t launches = 0, alg_bytes = 0;
 };
+
+static int expr_timing_collect(mlmc_expr *e) {
+    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+        float ms = 0.f;
+        MLMC_HIP_CHECK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+        e->ms_total += ms;
+    }
+    e->ev_used = 0;
+    return 0;
+}
 
 namespace mlmc {
 
@@ -49,74 +66,78 @@ __device__ __forceinline__ double np_maximum(double a, double b) { return (a >= 
 __device__ __forceinline__ double np_minimum(double a, double b) { return (a <= b || a != a) ? a : b; }
 __device__ __forceinline__ double np_sign(double a) { return a != a ? a : (a > 0.0 ? 1.0 : (a < 0.0 ? -1.0 : 0.0)); }
 
-template <bool PAIR>
+// Register file in LDS: [reg][side][slot][thread]; a thread works on S samples (slots) per instruction so that the
+// decode of an instruction and the latency of its loads are shared by S samples.
+template <bool PAIR, int S, bool HEAVY>
 __device__ __forceinline__ void binary(int op, double *d, const double *x, const double *y) {   // d may alias x or y
-    constexpr int S = PAIR ? 2 : 1;
+    constexpr int V = (PAIR ? 2 : 1) * S;
+    double r[V];
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < V; ++s) {
         const double a = x[s * X_THREADS], b = y[s * X_THREADS];
-        double r;
         switch (op) {
-            case MLMC_X_ADD: r = a + b; break;
-            case MLMC_X_SUB: r = a - b; break;
-            case MLMC_X_MUL: r = a * b; break;
-            case MLMC_X_DIV: r = a / b; break;
-            case MLMC_X_MOD: r = np_remainder(a, b); break;
-            case MLMC_X_POW: r = pow(a, b); break;
-            case MLMC_X_MAXIMUM: r = np_maximum(a, b); break;
-            case MLMC_X_MINIMUM: r = np_minimum(a, b); break;
-            case MLMC_X_FMAX: r = fmax(a, b); break;
-            case MLMC_X_FMIN: r = fmin(a, b); break;
-            case MLMC_X_ATAN2: r = atan2(a, b); break;
-            case MLMC_X_HYPOT: r = hypot(a, b); break;
-            case MLMC_X_FMOD: r = fmod(a, b); break;
-            case MLMC_X_AND: r = (a != 0.0 && b != 0.0) ? 1.0 : 0.0; break;
-            case MLMC_X_OR: r = (a != 0.0 || b != 0.0) ? 1.0 : 0.0; break;
-            default: r = ((a != 0.0) != (b != 0.0)) ? 1.0 : 0.0; break;   // XOR
+            case MLMC_X_ADD: r[s] = a + b; break;
+            case MLMC_X_SUB: r[s] = a - b; break;
+            case MLMC_X_MUL: r[s] = a * b; break;
+            case MLMC_X_DIV: r[s] = a / b; break;
+            case MLMC_X_MOD: if (HEAVY) r[s] = np_remainder(a, b); else r[s] = 0.0; break;
+            case MLMC_X_POW: if (HEAVY) r[s] = pow(a, b); else r[s] = 0.0; break;
+            case MLMC_X_MAXIMUM: r[s] = np_maximum(a, b); break;
+            case MLMC_X_MINIMUM: r[s] = np_minimum(a, b); break;
+            case MLMC_X_FMAX: r[s] = fmax(a, b); break;
+            case MLMC_X_FMIN: r[s] = fmin(a, b); break;
+            case MLMC_X_ATAN2: if (HEAVY) r[s] = atan2(a, b); else r[s] = 0.0; break;
+            case MLMC_X_HYPOT: if (HEAVY) r[s] = hypot(a, b); else r[s] = 0.0; break;
+            case MLMC_X_FMOD: if (HEAVY) r[s] = fmod(a, b); else r[s] = 0.0; break;
+            case MLMC_X_AND: r[s] = (a != 0.0 && b != 0.0) ? 1.0 : 0.0; break;
+            case MLMC_X_OR: r[s] = (a != 0.0 || b != 0.0) ? 1.0 : 0.0; break;
+            default: r[s] = ((a != 0.0) != (b != 0.0)) ? 1.0 : 0.0; break;   // XOR
         }
-        d[s * X_THREADS] = r;
     }
+#pragma unroll
+    for (int s = 0; s < V; ++s) d[s * X_THREADS] = r[s];
 }
 
-template <bool PAIR>
+template <bool PAIR, int S, bool HEAVY>
 __device__ __forceinline__ void unary(int op, double *d, const double *x) {
-    constexpr int S = PAIR ? 2 : 1;
+    constexpr int V = (PAIR ? 2 : 1) * S;
+    double r[V];
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < V; ++s) {
         const double a = x[s * X_THREADS];
-        double r;
         switch (op) {
-            case MLMC_X_NEG: r = -a; break;
-            case MLMC_X_ABS: r = fabs(a); break;
-            case MLMC_X_SQRT: r = sqrt(a); break;
-            case MLMC_X_SQUARE: r = a * a; break;
-            case MLMC_X_RECIP: r = 1.0 / a; break;
-            case MLMC_X_EXP: r = exp(a); break;
-            case MLMC_X_EXP2: r = exp2(a); break;
-            case MLMC_X_EXPM1: r = expm1(a); break;
-            case MLMC_X_LOG: r = log(a); break;
-            case MLMC_X_LOG2: r = log2(a); break;
-            case MLMC_X_LOG10: r = log10(a); break;
-            case MLMC_X_LOG1P: r = log1p(a); break;
-            case MLMC_X_SIN: r = sin(a); break;
-            case MLMC_X_COS: r = cos(a); break;
-            case MLMC_X_TAN: r = tan(a); break;
-            case MLMC_X_ASIN: r = asin(a); break;
-            case MLMC_X_ACOS: r = acos(a); break;
-            case MLMC_X_ATAN: r = atan(a); break;
-            case MLMC_X_SINH: r = sinh(a); break;
-            case MLMC_X_COSH: r = cosh(a); break;
-            case MLMC_X_TANH: r = tanh(a); break;
-            case MLMC_X_FLOOR: r = floor(a); break;
-            case MLMC_X_CEIL: r = ceil(a); break;
-            case MLMC_X_TRUNC: r = trunc(a); break;
-            case MLMC_X_RINT: r = rint(a); break;
-            case MLMC_X_SIGN: r = np_sign(a); break;
-            case MLMC_X_CBRT: r = cbrt(a); break;
-            default: r = (a == 0.0) ? 1.0 : 0.0; break;   // NOT
+            case MLMC_X_NEG: r[s] = -a; break;
+            case MLMC_X_ABS: r[s] = fabs(a); break;
+            case MLMC_X_SQRT: r[s] = sqrt(a); break;
+            case MLMC_X_SQUARE: r[s] = a * a; break;
+            case MLMC_X_RECIP: r[s] = 1.0 / a; break;
+            case MLMC_X_EXP: if (HEAVY) r[s] = exp(a); else r[s] = 0.0; break;
+            case MLMC_X_EXP2: if (HEAVY) r[s] = exp2(a); else r[s] = 0.0; break;
+            case MLMC_X_EXPM1: if (HEAVY) r[s] = expm1(a); else r[s] = 0.0; break;
+            case MLMC_X_LOG: if (HEAVY) r[s] = log(a); else r[s] = 0.0; break;
+            case MLMC_X_LOG2: if (HEAVY) r[s] = log2(a); else r[s] = 0.0; break;
+            case MLMC_X_LOG10: if (HEAVY) r[s] = log10(a); else r[s] = 0.0; break;
+            case MLMC_X_LOG1P: if (HEAVY) r[s] = log1p(a); else r[s] = 0.0; break;
+            case MLMC_X_SIN: if (HEAVY) r[s] = sin(a); else r[s] = 0.0; break;
+            case MLMC_X_COS: if (HEAVY) r[s] = cos(a); else r[s] = 0.0; break;
+            case MLMC_X_TAN: if (HEAVY) r[s] = tan(a); else r[s] = 0.0; break;
+            case MLMC_X_ASIN: if (HEAVY) r[s] = asin(a); else r[s] = 0.0; break;
+            case MLMC_X_ACOS: if (HEAVY) r[s] = acos(a); else r[s] = 0.0; break;
+            case MLMC_X_ATAN: if (HEAVY) r[s] = atan(a); else r[s] = 0.0; break;
+            case MLMC_X_SINH: if (HEAVY) r[s] = sinh(a); else r[s] = 0.0; break;
+            case MLMC_X_COSH: if (HEAVY) r[s] = cosh(a); else r[s] = 0.0; break;
+            case MLMC_X_TANH: if (HEAVY) r[s] = tanh(a); else r[s] = 0.0; break;
+            case MLMC_X_FLOOR: r[s] = floor(a); break;
+            case MLMC_X_CEIL: r[s] = ceil(a); break;
+            case MLMC_X_TRUNC: r[s] = trunc(a); break;
+            case MLMC_X_RINT: r[s] = rint(a); break;
+            case MLMC_X_SIGN: r[s] = np_sign(a); break;
+            case MLMC_X_CBRT: if (HEAVY) r[s] = cbrt(a); else r[s] = 0.0; break;
+            default: r[s] = (a == 0.0) ? 1.0 : 0.0; break;   // NOT
         }
-        d[s * X_THREADS] = r;
     }
+#pragma unroll
+    for (int s = 0; s < V; ++s) d[s * X_THREADS] = r[s];
 }
 
 __device__ __forceinline__ bool compare(int op, double a, double b) {
@@ -130,61 +151,100 @@ __device__ __forceinline__ bool compare(int op, double a, double b) {
     }
 }
 
-// One thread = one sample; the program counter is uniform over the grid, so every branch below is a scalar branch.
 constexpr int X_TABLE_ROWS = 64;   // row pointers passed by value in the kernel arguments (no table upload)
 struct RowTable {
     const double *p[X_TABLE_ROWS];
 };
 
-template <bool PAIR>
+// The program counter is uniform over the grid, so every branch below is a scalar branch.  A block covers
+// S * X_THREADS consecutive samples; slot k of thread t is sample base + k * X_THREADS + t (coalesced per slot).
+// HEAVY = false leaves out the libm-backed operations (exp, log, trigonometry, pow, fmod): their register demand
+// (~240 VGPRs, two waves per SIMD) would otherwise set the occupancy of every program, and this kernel lives on
+// memory-level parallelism.
+template <bool PAIR, int S, bool HEAVY>
 __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__restrict__ prog, int n_instr, RowTable tab,
                                                     const double *const *__restrict__ rows, int64_t n, int n_regs,
                                                     double *__restrict__ out_f, double *__restrict__ out_c,
                                                     uint8_t *__restrict__ keep_out) {
-    extern __shared__ double regs[];   // [n_regs][2][X_THREADS]
-    const int64_t i = (int64_t)blockIdx.x * X_THREADS + threadIdx.x;
-    const bool active = i < n;
+    extern __shared__ double regs[];   // [n_regs][sides][S][X_THREADS]
+    constexpr int SIDES = PAIR ? 2 : 1;
+    constexpr int REG_STRIDE = SIDES * S * X_THREADS;
+    const int64_t i0 = (int64_t)blockIdx.x * (S * X_THREADS) + threadIdx.x;
     double *const mine = regs + threadIdx.x;
-    bool keep = true;
+    bool keep[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) keep[k] = true;
     for (int pc = 0; pc < n_instr; ++pc) {
         const mlmc_expr_instr ins = prog[pc];
-        double *const d = mine + (size_t)ins.dst * 2 * X_THREADS;
-        const double *const x = mine + (size_t)ins.a * 2 * X_THREADS;
-        const double *const y = mine + (size_t)ins.b * 2 * X_THREADS;
+        double *const d = mine + (size_t)ins.dst * REG_STRIDE;
+        const double *const x = mine + (size_t)ins.a * REG_STRIDE;
+        const double *const y = mine + (size_t)ins.b * REG_STRIDE;
         const int op = ins.op;
         if (op == MLMC_X_LOAD) {
             const double *__restrict__ row = rows ? rows[ins.a] : tab.p[ins.a];
             if (PAIR) {
-                double2 v = make_double2(0.0, 0.0);
-                if (active) v = reinterpret_cast<const double2 *>(row)[i];
-                d[0] = v.x;
-                d[X_THREADS] = v.y;
+                double2 v[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) {       // S independent 128-bit loads in flight
+                    const int64_t i = i0 + (int64_t)k * X_THREADS;
+                    v[k] = i < n ? reinterpret_cast<const double2 *>(row)[i] : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    d[k * X_THREADS] = v[k].x;
+                    d[(S + k) * X_THREADS] = v[k].y;
+                }
             } else {
-                d[0] = active ? row[i] : 0.0;
+                double v[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const int64_t i = i0 + (int64_t)k * X_THREADS;
+                    v[k] = i < n ? row[i] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < S; ++k) d[k * X_THREADS] = v[k];
+            }
+        } else if (op == MLMC_X_STORE) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const int64_t i = i0 + (int64_t)k * X_THREADS;
+                if (i < n) {
+                    out_f[(int64_t)ins.b * n + i] = x[k * X_THREADS];
+                    if (PAIR) out_c[(int64_t)ins.b * n + i] = x[(S + k) * X_THREADS];
+                }
             }
         } else if (op == MLMC_X_CONST) {
-            d[0] = ins.imm;
-            if (PAIR) d[X_THREADS] = ins.imm;
-        } else if (op == MLMC_X_STORE) {
-            if (active) {
-                out_f[(int64_t)ins.b * n + i] = x[0];
-                if (PAIR) out_c[(int64_t)ins.b * n + i] = x[X_THREADS];
-            }
+#pragma unroll
+            for (int s = 0; s < SIDES * S; ++s) d[s * X_THREADS] = ins.imm;
         } else if (op == MLMC_X_SELECT) {
-            keep = keep && (x[0] != 0.0);
+#pragma unroll
+            for (int k = 0; k < S; ++k) keep[k] = keep[k] && (x[k * X_THREADS] != 0.0);
         } else if (op >= MLMC_X_LT && op <= MLMC_X_NE) {
-            bool r = compare(op, x[0], y[0]);
-            if (PAIR) r = compare(op, x[X_THREADS], y[X_THREADS]) && r;
-            const double v = r ? 1.0 : 0.0;
-            d[0] = v;
-            if (PAIR) d[X_THREADS] = v;
+            double v[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                bool r = compare(op, x[k * X_THREADS], y[k * X_THREADS]);
+                if (PAIR) r = compare(op, x[(S + k) * X_THREADS], y[(S + k) * X_THREADS]) && r;
+                v[k] = r ? 1.0 : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                d[k * X_THREADS] = v[k];
+                if (PAIR) d[(S + k) * X_THREADS] = v[k];
+            }
         } else if ((op >= MLMC_X_ADD && op <= MLMC_X_FMOD) || op == MLMC_X_AND || op == MLMC_X_OR || op == MLMC_X_XOR) {
-            binary<PAIR>(op, d, x, y);
+            binary<PAIR, S, HEAVY>(op, d, x, y);
         } else {
-            unary<PAIR>(op, d, x);
+            unary<PAIR, S, HEAVY>(op, d, x);
         }
     }
-    if (keep_out && active) keep_out[i] = keep ? 1 : 0;
+    if (keep_out) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int64_t i = i0 + (int64_t)k * X_THREADS;
+            if (i < n) keep_out[i] = keep[k] ? 1 : 0;
+        }
+    }
 }
 
 // ---- order-preserving compaction of the selected samples --------------------------------------------------------
@@ -263,7 +323,7 @@ int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_reg
     if (n_instr < 1 || n_instr > MLMC_EXPR_MAX_INSTR) return fail("mlmc_expr_create: program length out of range");
     if (n_regs < 1 || n_regs > MLMC_EXPR_MAX_REGS) return fail("mlmc_expr_create: register count out of range");
     if (n_in_rows < 1 || n_out_rows < 1) return fail("mlmc_expr_create: a program needs input and output rows");
-    bool selects = false;
+    bool selects = false, heavy = false;
     std::vector<char> written(n_regs, 0), stored(n_out_rows, 0);
     for (int k = 0; k < n_instr; ++k) {   // validate: the kernel trusts every index
         const mlmc_expr_instr &in = prog[k];
@@ -284,6 +344,13 @@ int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_reg
             written[in.dst] = 1;
         }
         if (in.op == MLMC_X_SELECT) selects = true;
+        switch (in.op) {
+            case MLMC_X_MOD: case MLMC_X_POW: case MLMC_X_ATAN2: case MLMC_X_HYPOT: case MLMC_X_FMOD: case MLMC_X_EXP:
+            case MLMC_X_EXP2: case MLMC_X_EXPM1: case MLMC_X_LOG: case MLMC_X_LOG2: case MLMC_X_LOG10: case MLMC_X_LOG1P:
+            case MLMC_X_SIN: case MLMC_X_COS: case MLMC_X_TAN: case MLMC_X_ASIN: case MLMC_X_ACOS: case MLMC_X_ATAN:
+            case MLMC_X_SINH: case MLMC_X_COSH: case MLMC_X_TANH: case MLMC_X_CBRT: heavy = true; break;
+            default: break;
+        }
     }
     for (int r = 0; r < n_out_rows; ++r)
         if (!stored[r]) return fail("mlmc_expr_create: an output row is never stored");
@@ -294,6 +361,7 @@ int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_reg
     e->n_in = n_in_rows;
     e->n_out = n_out_rows;
     e->selects = selects;
+    e->heavy = heavy;
     if (hipMalloc(&e->d_prog, sizeof(mlmc_expr_instr) * n_instr) != hipSuccess ||
         hipMalloc(&e->d_rows, sizeof(double *) * n_in_rows) != hipSuccess ||
         hipHostMalloc(&e->h_total, sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
@@ -312,6 +380,7 @@ void mlmc_expr_destroy(mlmc_expr *e) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_total) (void)hipHostFree(e->h_total);
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -352,15 +421,55 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
         tc = has_coarse ? e->d_tmp_c : nullptr;
         keep = e->d_keep;
     }
-    const size_t lds = sizeof(double) * (size_t)e->n_regs * 2 * X_THREADS;
-    const unsigned blocks = (unsigned)((n + X_THREADS - 1) / X_THREADS);
-    if (has_coarse)
-        hipLaunchKernelGGL(k_expr<true>, dim3(blocks), dim3(X_THREADS), lds, st, e->d_prog, (int)e->prog.size(), tab, d_rows, n,
-                           e->n_regs, tf, tc, keep);
-    else
-        hipLaunchKernelGGL(k_expr<false>, dim3(blocks), dim3(X_THREADS), lds, st, e->d_prog, (int)e->prog.size(), tab, d_rows, n,
-                           e->n_regs, tf, tc, keep);
+    // samples per thread: two for the light kernel (measured best: 5.3-6.1 TB/s on copy / arithmetic programs), up to
+    // four for the ALU-bound libm kernel, as long as the register file of a block stays within 32 KB of LDS
+    const int sides = has_coarse ? 2 : 1;
+    const int s_max = e->heavy ? 4 : 2;
+    int S = 1;
+    while (S < s_max && (size_t)e->n_regs * sides * (2 * S) * X_THREADS * sizeof(double) <= 32768) S *= 2;
+    if (const char *force = getenv("MLMC_EXPR_SLOTS")) {   // tuning aid
+        const int f = atoi(force);
+        if ((f == 1 || f == 2 || f == 4) && (size_t)e->n_regs * sides * f * X_THREADS * sizeof(double) <= 65536) S = f;
+    }
+    const size_t lds = sizeof(double) * (size_t)e->n_regs * sides * S * X_THREADS;
+    const unsigned blocks = (unsigned)((n + (int64_t)S * X_THREADS - 1) / ((int64_t)S * X_THREADS));
+    const int n_instr = (int)e->prog.size();
+    const bool timed = (rt().flags & 1) != 0;
+    if (timed) {
+        if (e->ev_used >= 8192) {
+            MLMC_HIP_CHECK(hipEventSynchronize(e->ev[e->ev_used - 1]));
+            if (int rc = expr_timing_collect(e)) return rc;
+        }
+        if (e->ev_used + 2 > e->ev.size()) {
+            hipEvent_t e0, e1;
+            MLMC_HIP_CHECK(hipEventCreate(&e0));
+            MLMC_HIP_CHECK(hipEventCreate(&e1));
+            e->ev.push_back(e0);
+            e->ev.push_back(e1);
+        }
+        MLMC_HIP_CHECK(hipEventRecord(e->ev[e->ev_used], st));
+    }
+#define MLMC_X_LAUNCH(P, SS, H)                                                                                            \
+    hipLaunchKernelGGL((k_expr<P, SS, H>), dim3(blocks), dim3(X_THREADS), lds, st, e->d_prog, n_instr, tab, d_rows, n, e->n_regs, \
+                       tf, tc, keep)
+#define MLMC_X_LAUNCH_S(P, H)                                                                                              \
+    do {                                                                                                                   \
+        if (S == 4) MLMC_X_LAUNCH(P, 4, H); else if (S == 2) MLMC_X_LAUNCH(P, 2, H); else MLMC_X_LAUNCH(P, 1, H);          \
+    } while (0)
+    if (has_coarse) {
+        if (e->heavy) MLMC_X_LAUNCH_S(true, true); else MLMC_X_LAUNCH_S(true, false);
+    } else {
+        if (e->heavy) MLMC_X_LAUNCH_S(false, true); else MLMC_X_LAUNCH_S(false, false);
+    }
+#undef MLMC_X_LAUNCH_S
+#undef MLMC_X_LAUNCH
     MLMC_HIP_CHECK(hipGetLastError());
+    if (timed) {
+        MLMC_HIP_CHECK(hipEventRecord(e->ev[e->ev_used + 1], st));
+        e->ev_used += 2;
+    }
+    e->launches += 1;
+    e->alg_bytes += (int64_t)sizeof(double) * sides * n * (e->n_in + e->n_out);   // every referenced row in, every result row out
     if (!e->selects) return 0;
     hipLaunchKernelGGL(k_keep_counts, dim3(nblk), dim3(X_THREADS), 0, st, keep, n, e->d_offsets);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, e->d_offsets, nblk, e->h_total);
@@ -369,6 +478,21 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
     MLMC_HIP_CHECK(hipGetLastError());
     MLMC_HIP_CHECK(hipStreamSynchronize(st));
     if (n_selected) *n_selected = *e->h_total;
+    return 0;
+}
+
+int mlmc_expr_kernel_time(mlmc_expr *e, double *ms, int64_t *launches, int64_t *alg_bytes) {
+    if (!e) return fail("mlmc_expr_kernel_time: null argument");
+    if (e->ev_used) {
+        MLMC_HIP_CHECK(hipEventSynchronize(e->ev[e->ev_used - 1]));
+        if (int rc = expr_timing_collect(e)) return rc;
+    }
+    if (ms) *ms = e->ms_total;
+    if (launches) *launches = e->launches;
+    if (alg_bytes) *alg_bytes = e->alg_bytes;
+    e->ms_total = 0;
+    e->launches = 0;
+    e->alg_bytes = 0;
     return 0;
 }
 

@@ -336,6 +336,12 @@ class DevicePlan:
             coarse = coarse[:self.n_out * k].view(self.n_out, k)
         return fine, coarse, rows                      # the inputs stay referenced until the caller has finalized
 
+    def kernel_time(self):
+        """(ms, launches, algorithmic bytes) of the evaluation kernel since the previous call (needs FLAG_TIMING)."""
+        ms, launches, nbytes = C.c_double(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().mlmc_expr_kernel_time(self.handle(), C.byref(ms), C.byref(launches), C.byref(nbytes)))
+        return ms.value, launches.value, nbytes.value
+
     def __del__(self):
         try:
             if self._handle is not None and _lib._lib is not None:
