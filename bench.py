@@ -311,6 +311,7 @@ def tree_bench(args, cfg, world, rank, dev, dist):
     x_ms, x_launches, x_bytes = plan.kernel_time()
     a_ms, a_launches, _ = acc.kernel_time()
     gbs = (x_bytes / 1e9) / (x_ms / 1e3) if x_ms > 0 else 0.0
+    traffic, traffic_src = pmc_avg_bytes_per_dispatch(args.config, "k_expr")
     out = {
         "metric": "moment-evals/sec (samples x n_moments)", "value": world * L * n_l * R * args.steps / elapsed,
         "unit": "moment-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -320,7 +321,7 @@ def tree_bench(args, cfg, world, rank, dev, dist):
                    "tree": "(x - 0.1) * (x - 0.1) / (np.abs(y) + 1.0)", "program_instructions": len(plan.prog),
                    "program_registers": plan.n_regs, "stored_rows_read": len(plan.in_rows), "result_rows": plan.n_out},
         "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_expr",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_expr",
                      "avg_launch_ms": round(x_ms / max(x_launches, 1), 5),
                      "alg_bytes_per_launch": int(x_bytes / max(x_launches, 1)), "launches_per_step": x_launches // max(args.steps, 1),
                      "moments_kernel_ms_per_step": round(a_ms / max(args.steps, 1), 5)},
@@ -412,6 +413,28 @@ def pmc_traffic_per_launch(config, kname, n_l, L, launches_per_step):
     steps_prof = max(1, round(read_b / levels_bytes))
     per_step = (read_b + write_b) / steps_prof
     return int(per_step / max(launches_per_step, 1)), os.path.basename(files[-1])
+
+
+def pmc_avg_bytes_per_dispatch(config, kname):
+    """Average HBM bytes per dispatch of the kernels matching `kname` from the committed PMC passes (same corrections as
+    pmc_traffic_per_launch)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_config{}.json".format(config))))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        prof = json.load(f)
+    total = 0.0
+    n_disp = 0
+    for name, e in prof.items():
+        if kname not in name or "FETCH_SIZE_avg_per_dispatch" not in e:
+            continue
+        d = e.get("dispatches_fetch", 0)
+        total += (2.0 * e["FETCH_SIZE_avg_per_dispatch"] + e.get("WRITE_SIZE_avg_per_dispatch", 0.0)) * 1024.0 * d
+        n_disp += d
+    if n_disp == 0:
+        return None, None
+    return int(total / n_disp), os.path.basename(files[-1])
 
 
 def cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_stats):

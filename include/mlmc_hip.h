@@ -197,6 +197,16 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
  * row) of the evaluation kernel since create or the previous call; same contract as mlmc_accum_kernel_time. */
 int mlmc_expr_kernel_time(mlmc_expr *e, double *ms, int64_t *launches, int64_t *alg_bytes);
 
+/* ---- bootstrap sub-sampling (Quantity.pick_samples, mlmc/quantity/quantity.py:308-325; Estimate.est_bootstrap,
+ * mlmc/estimator.py:171-205) ------------------------------------------------------------------------------------
+ * out[r][j] = in[r][idx_j], j < k, idx_j uniform in [0, n) with replacement (RNG.choice(chunk, size=k, axis=1)); the
+ * same idx_j for every row and for fine and coarse.  idx_j comes from Philox4x32-10 keyed by `seed` with counter j, so a
+ * draw is reproducible from (seed, n, k) alone; the reference's generator is an unseeded module global, parity is
+ * statistical only.  All pointers are DEVICE pointers: fine / coarse [n_rows][n] (coarse may be NULL),
+ * fine_out / coarse_out [n_rows][k].  Asynchronous on the library's stream. */
+int mlmc_subsample_gather(const double *fine, const double *coarse, int32_t n_rows, int64_t n, int64_t k, uint64_t seed,
+                          double *fine_out, double *coarse_out);
+
 #ifdef __cplusplus
 }
 #endif

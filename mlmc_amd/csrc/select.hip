@@ -154,3 +154,56 @@ extern "C" int mlmc_percentiles(const double *x, int64_t n, const double *q_perc
     if (own) (void)hipFree(d_x);
     return rc;
 }
+
+// ------------------------------------------------------------------------------------------
+// Bootstrap sub-sampling: gather of k uniformly drawn columns (with replacement) of a resident chunk.
+// Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, counter = draw index: every draw is independent of the launch
+// geometry.  index = high 64 bits of (64 random bits x n): uniform on [0, n) up to a bias below n / 2^64.
+// ------------------------------------------------------------------------------------------
+namespace mlmc {
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ uint64_t philox_u64(uint64_t counter, uint64_t seed) {
+    uint32_t c[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return ((uint64_t)c[1] << 32) | c[0];
+}
+
+__global__ __launch_bounds__(256) void k_subsample_gather(const double *__restrict__ fine, const double *__restrict__ coarse,
+                                                          int n_rows, int64_t n, int64_t k, uint64_t seed,
+                                                          double *__restrict__ fine_out, double *__restrict__ coarse_out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    const int64_t idx = (int64_t)__umul64hi(philox_u64((uint64_t)j, seed), (uint64_t)n);
+    for (int r = 0; r < n_rows; ++r) {
+        fine_out[(int64_t)r * k + j] = fine[(int64_t)r * n + idx];
+        if (coarse) coarse_out[(int64_t)r * k + j] = coarse[(int64_t)r * n + idx];
+    }
+}
+
+}  // namespace mlmc
+
+extern "C" int mlmc_subsample_gather(const double *fine, const double *coarse, int32_t n_rows, int64_t n, int64_t k,
+                                     uint64_t seed, double *fine_out, double *coarse_out) {
+    using namespace mlmc;
+    if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
+    if (!fine || !fine_out || (coarse && !coarse_out)) return fail("mlmc_subsample_gather: null argument");
+    if (n_rows < 1 || n < 1 || k < 0) return fail("mlmc_subsample_gather: sizes out of range");
+    if (k == 0) return 0;
+    hipLaunchKernelGGL(k_subsample_gather, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, rt().stream, fine, coarse, n_rows, n, k,
+                       seed, fine_out, coarse_out);
+    MLMC_HIP_CHECK(hipGetLastError());
+    return 0;
+}

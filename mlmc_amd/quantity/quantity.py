@@ -243,6 +243,7 @@ class Quantity:
         picked = Quantity(quantity_type=self.qtype.replace_scalar(qt.BoolType()), input_quantities=[self, params_q],
                           operation=Quantity.pick_samples)
         picked._volatile = True          # a fresh random draw on every evaluation: never cached on the device
+        picked._sym = ("subsample", per_level)   # estimate_mean draws the columns on the device (mlmc_subsample_gather)
         return picked
 
     # ---- indexing -------------------------------------------------------------------------------------

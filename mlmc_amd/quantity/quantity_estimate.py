@@ -231,6 +231,59 @@ def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache):
     return fine, coarse
 
 
+def _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache):
+    """Sample rows of `source` for one storage chunk, ready for the accumulators: (fine [M, n], coarse [M, n] | None) as
+    torch CUDA tensors (resident: served from / added to the HBM cache) or, when the chunk does not fit the cache budget
+    and the tree is evaluated on the host, as NumPy arrays that go through the staging buffer of the C ABI."""
+    sl = chunk_spec.chunk_slice
+    key = (id(source), chunk_spec.level_id, chunk_spec.chunk_id, None if sl is None else (sl.start, sl.stop),
+           None if n_collected is None else n_collected[int(chunk_spec.level_id)])
+    item = _device_cache.get(key) if use_cache else None
+    if item is not None:
+        return item[0], item[1]
+    if plan is not None:
+        got = _evaluate_on_device(plan, chunk_spec, key[1:], use_cache)
+        if got is None:
+            import torch
+            return torch.empty((plan.n_out, 0), dtype=torch.float64), None
+        if use_cache:
+            _device_cache.put_tensors(key, got[0], got[1], owner=source)
+        return got
+    raw = source.samples(chunk_spec)                             # [M, n, 2|1], host evaluation of the tree
+    if raw.shape[1] == 0:
+        return np.empty((raw.shape[0], 0)), None
+    fine, coarse = _split_fine_coarse(raw, chunk_spec.level_id)
+    item = _device_cache.put(key, fine, coarse, owner=source) if use_cache else None
+    if item is None:
+        return fine, coarse                                      # not cached: staged through the C ABI
+    return item[0], item[1]
+
+
+def _subsample_on_device(pair, params):
+    """Quantity.pick_samples (reference quantity.py:308-325) on the device: the chunk's share of the k-of-n sub-sample is
+    drawn on the host (hypergeometric count, as in the reference), the `size` columns -- uniform with replacement,
+    RNG.choice(chunk, size, axis=1) -- are gathered by mlmc_subsample_gather with a counter-based generator."""
+    import scipy.stats
+    import torch
+    from .. import _lib
+    fine, coarse = pair
+    n = fine.shape[-1]
+    size = int(scipy.stats.hypergeom(params._orig_n, params._orig_k, n).rvs(size=1, random_state=qmod.RNG)[0])
+    seed = int(qmod.RNG.integers(0, 2 ** 63 - 1))
+    if not isinstance(fine, torch.Tensor):                       # host chunk (over the cache budget): upload for the gather
+        dev = torch.device("cuda", _lib_device())
+        fine = torch.from_numpy(np.ascontiguousarray(fine)).to(dev)
+        coarse = None if coarse is None else torch.from_numpy(np.ascontiguousarray(coarse)).to(dev)
+        torch.cuda.current_stream(dev).synchronize()
+    m = fine.shape[0]
+    out_f = torch.empty((m, size), dtype=torch.float64, device=fine.device)
+    out_c = None if coarse is None else torch.empty((m, size), dtype=torch.float64, device=fine.device)
+    if size > 0:
+        _lib.check(_lib.lib().mlmc_subsample_gather(fine.data_ptr(), None if coarse is None else coarse.data_ptr(), m, n, size,
+                                                    seed, out_f.data_ptr(), None if out_c is None else out_c.data_ptr()))
+    return out_f, out_c
+
+
 def estimate_mean(quantity, group=None):
     """MLMC mean estimator (reference: quantity_estimate.py:22-80).
 
@@ -253,6 +306,14 @@ def estimate_mean(quantity, group=None):
     else:
         source, fn, mode, rows_per_comp = quantity, None, engine.LevelAccumulator.MOMENTS, 1
 
+    # bootstrap sub-sample of a quantity (Quantity.subsample): the chunks of the underlying quantity stay resident in HBM,
+    # every estimate draws its random columns on the device (mlmc_subsample_gather)
+    subsample_params = None
+    sym = source.__dict__.get("_sym")
+    if sym is not None and sym[0] == "subsample" and _device_tree_enabled():
+        subsample_params = sym[1]
+        source = source._input_quantities[0]
+
     # a tree of per-sample nodes runs as one device program over the stored rows (quantity/lowering.py)
     plan = lowering.plan_for(source) if _device_tree_enabled() else None
     acc = None
@@ -264,36 +325,15 @@ def estimate_mean(quantity, group=None):
         n_collected = None
         use_cache = False
     for chunk_spec in storage_q.chunks():
-        sl = chunk_spec.chunk_slice
-        key = (id(source), chunk_spec.level_id, chunk_spec.chunk_id, None if sl is None else (sl.start, sl.stop),
-               None if n_collected is None else n_collected[int(chunk_spec.level_id)])
-        item = _device_cache.get(key) if use_cache else None
-        if item is None and plan is not None:
-            got = _evaluate_on_device(plan, chunk_spec, key[1:], use_cache)
-            if got is None:
-                if acc is None:
-                    n_comp = plan.n_out
-                    acc = _acc_pool.take(fn, n_levels, mode, n_comp)
-                continue
-            item = (_device_cache.put_tensors(key, got[0], got[1], owner=source) if use_cache
-                    else (got[0], got[1], 0, None))
-        if item is None:
-            raw = source.samples(chunk_spec)                     # [M, n, 2|1]
-            if raw.shape[1] == 0:
-                if acc is None:
-                    n_comp = raw.shape[0]
-                    acc = _acc_pool.take(fn, n_levels, mode, n_comp)
-                continue
-            fine, coarse = _split_fine_coarse(raw, chunk_spec.level_id)
-            item = _device_cache.put(key, fine, coarse, owner=source) if use_cache else None
-            if item is None:
-                item = (fine, coarse, 0, None)                    # not cached: staged through the C ABI
-        fine, coarse = item[0], item[1]
-        if fine.shape[-1] == 0:                                   # every sample of the chunk was deselected
-            if acc is None:
-                n_comp = fine.shape[0]
+        pair = _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache)     # (fine [M, n], coarse | None)
+        if pair is not None and subsample_params is not None and pair[0].shape[-1] > 0:
+            pair = _subsample_on_device(pair, subsample_params[int(chunk_spec.level_id)])
+        if pair is None or pair[0].shape[-1] == 0:               # empty chunk / every sample deselected
+            if acc is None and pair is not None:
+                n_comp = pair[0].shape[0]
                 acc = _acc_pool.take(fn, n_levels, mode, n_comp)
             continue
+        fine, coarse = pair
         if acc is None:
             n_comp = fine.shape[0]
             assert n_comp * rows_per_comp == quantity_vec_size

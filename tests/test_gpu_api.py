@@ -526,3 +526,59 @@ def test_device_tree_shares_stored_rows_between_quantities(hip):
     qe.estimate_mean(qe.moments(x * y, fn))              # one more stored row
     assert cache.uploads - u0 == 6
     qe.device_cache_clear()
+
+
+def test_device_subsample_gather(hip):
+    """mlmc_subsample_gather: every output column is a column of the input (same index for all rows and for fine and
+    coarse), the draw is reproducible from the seed, indices are uniform; and the estimate over a sub-sampled quantity
+    is reproducible once the host generator that draws counts and seeds is seeded."""
+    import ctypes as C
+    import torch
+    from mlmc_amd import Legendre
+    from mlmc_amd.quantity import quantity as qmod, quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    dev = torch.device("cuda", 0)
+    n, k, m = 5000, 200000, 3
+    fine = (torch.arange(n, dtype=torch.float64, device=dev)[None, :] + 10000.0 * torch.arange(m, dtype=torch.float64, device=dev)[:, None]).contiguous()
+    coarse = (-fine).contiguous()
+    outs = []
+    for seed in (11, 11, 12):
+        of = torch.empty((m, k), dtype=torch.float64, device=dev)
+        oc = torch.empty((m, k), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        hip.check(hip.lib().mlmc_subsample_gather(fine.data_ptr(), coarse.data_ptr(), m, n, k, seed, of.data_ptr(), oc.data_ptr()))
+        hip.check(hip.lib().mlmc_synchronize())
+        outs.append((of.cpu().numpy(), oc.cpu().numpy()))
+    f0, c0 = outs[0]
+    idx = f0[0].astype(np.int64)
+    assert idx.min() >= 0 and idx.max() < n
+    for r in range(m):
+        assert np.array_equal(f0[r], idx + 10000.0 * r) and np.array_equal(c0[r], -(idx + 10000.0 * r))
+    assert np.array_equal(outs[1][0], f0) and not np.array_equal(outs[2][0], f0)
+    counts = np.bincount(idx, minlength=n)                           # expected 40 per index
+    assert abs(counts.mean() - k / n) < 1e-9 and counts.std() < 1.25 * np.sqrt(k / n) and counts.min() > 0
+    assert abs(np.corrcoef(idx[:-1], idx[1:])[0, 1]) < 0.01
+
+    # estimates over a sub-sampled quantity: device path, reproducible with a seeded host generator
+    steps = [0.5, 0.07]
+    levels = level_arrays([30000, 8000], steps, 1, 0)
+    st = _storage(levels, steps, _scalar_spec())
+    q = make_root_quantity(st, _scalar_spec())['q'][1]['0'][0, 0]
+    fn = Legendre(5, (-3.7190164854556804, 3.7190164854556804))
+    sub = q.subsample([3000, 800])
+    res = []
+    for seed in (5, 5, 6):
+        qmod.RNG = np.random.default_rng(seed)
+        res.append(qe.estimate_mean(qe.moments(sub, fn)))
+    assert res[0].n_samples.tolist() == [3000, 800] or sum(res[0].n_samples) + sum(res[0].n_rm_samples) == 3800
+    assert np.array_equal(res[0].mean, res[1].mean) and not np.array_equal(res[0].mean, res[2].mean)
+    full = qe.estimate_mean(qe.moments(q, fn))
+    z = (res[0].mean[1:] - full.mean[1:]) / np.sqrt(res[0].var[1:])
+    assert np.all(np.abs(z) < 5), z
+    # the same tree on the host path (MLMC_HIP_DEVICE_TREE=0) keeps working
+    os.environ["MLMC_HIP_DEVICE_TREE"] = "0"
+    try:
+        host = qe.estimate_mean(qe.moments(sub, fn))
+        assert sum(host.n_samples) + sum(host.n_rm_samples) == 3800
+    finally:
+        os.environ.pop("MLMC_HIP_DEVICE_TREE", None)

@@ -18,7 +18,7 @@ def one(pattern):
     return f[0] if f else None
 
 
-for cfg in ("c2", "c3"):
+for cfg in ("c2", "c3", "c6"):
     f = one(f"trace_{cfg}/*/*_kernel_stats.csv")
     if f:
         rows = list(csv.DictReader(open(f)))
