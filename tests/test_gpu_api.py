@@ -582,3 +582,43 @@ def test_device_subsample_gather(hip):
         assert sum(host.n_samples) + sum(host.n_rm_samples) == 3800
     finally:
         os.environ.pop("MLMC_HIP_DEVICE_TREE", None)
+
+
+@pytest.mark.parametrize("seed", [0, 3, 7, 11])
+def test_device_tree_random_trees(hip, seed):
+    """Random trees over IEEE-exact operators (+ - * / % sqrt floor sign max min, comparisons, select): the device rows
+    equal the host tree's bit for bit."""
+    import torch
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from tests.test_lowering import _random_tree, _scalar, _spec, host_chunk, make_storage
+    rng = np.random.default_rng(1000 + seed)
+    st = make_storage((1500, 900, 700), seed=seed)
+    root = make_root_quantity(st, _spec())
+    leaves = [root['length'][1]['10'][0], root['length'][2]['20'][1], root['width'][3]['30'][0], root['width'][2]['40'],
+              root['length'].time_interpolation(1.25)['10']]
+    dev = torch.device("cuda", 0)
+    n_checked = 0
+    for _ in range(6):
+        q = _random_tree(rng, leaves, depth=4)
+        if rng.random() < 0.5:
+            m1 = _scalar(rng, leaves, 2) > float(rng.normal() + 2.0)
+            m2 = _scalar(rng, leaves, 2) <= float(rng.normal() + 3.0)
+            q = q.select(m1, m2) if rng.random() < 0.5 else q.select(np.logical_or(m1, m2))
+        plan = lowering.plan_for(q)
+        if plan is None:
+            continue
+        for chunk in st.chunks():
+            stored = st.sample_pairs_level(chunk)
+            with np.errstate(all="ignore"):
+                want = host_chunk(q, chunk)
+            rows = [torch.from_numpy(np.ascontiguousarray(stored[r])).to(dev) for r in plan.in_rows]
+            torch.cuda.synchronize()
+            f, c, _ = plan.evaluate(rows, has_coarse=(stored.shape[-1] == 2), n=stored.shape[1], sync=True)
+            got = f.cpu().numpy()[:, :, None]
+            if c is not None:
+                got = np.concatenate([got, c.cpu().numpy()[:, :, None]], axis=2)
+            assert got.shape == want.shape
+            assert np.array_equal(got, want, equal_nan=True), (seed, np.nanmax(np.abs(got - want)))
+            n_checked += 1
+    assert n_checked >= 6

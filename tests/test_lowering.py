@@ -149,3 +149,58 @@ def test_header_opcodes_match_the_python_table():
     assert names == lowering._OP_NAMES
     assert int(re.search(r"MLMC_EXPR_MAX_REGS (\d+)", hdr).group(1)) == lowering.MAX_REGS
     assert int(re.search(r"MLMC_EXPR_MAX_INSTR (\d+)", hdr).group(1)) == lowering.MAX_INSTR
+
+
+def _random_tree(rng, leaves, depth):
+    """Random per-sample expression over the given scalar / vector quantities (operators the reference's Quantity has)."""
+    if depth == 0 or rng.random() < 0.15:
+        return leaves[rng.integers(len(leaves))]
+    kind = rng.integers(7)
+    a = _random_tree(rng, leaves, depth - 1)
+    if kind == 0:
+        return a + float(rng.normal())
+    if kind == 1:
+        return float(rng.normal()) - a
+    if kind == 2:
+        b = _random_tree(rng, leaves, depth - 1)
+        return a * b if a.size() == b.size() or min(a.size(), b.size()) == 1 else a * 0.5
+    if kind == 3:
+        return a / (np.abs(_scalar(rng, leaves, depth - 1)) + 1.0)
+    if kind == 4:
+        f = [np.sqrt, np.square, np.negative, np.floor, np.sign][rng.integers(5)]
+        return f(np.abs(a)) if f is np.sqrt else f(a)
+    if kind == 5:
+        b = _scalar(rng, leaves, depth - 1)
+        return [np.maximum, np.minimum, np.fmax, np.subtract][rng.integers(4)](a, b)
+    return a % (np.abs(_scalar(rng, leaves, depth - 1)) + 0.5)
+
+
+def _scalar(rng, leaves, depth):
+    q = _random_tree(rng, leaves, depth)
+    return q if q.size() == 1 else q[0]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_trees_lower_to_equivalent_programs(seed):
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    rng = np.random.default_rng(1000 + seed)
+    st = make_storage((120, 90, 60), seed=seed)
+    root = make_root_quantity(st, _spec())
+    leaves = [root['length'][1]['10'][0], root['length'][2]['20'][1], root['width'][3]['30'][0], root['width'][2]['40'],
+              root['length'].time_interpolation(1.25)['10']]
+    for _ in range(6):
+        q = _random_tree(rng, leaves, depth=4)
+        if rng.random() < 0.5:                           # half of the trees also select samples
+            m1 = _scalar(rng, leaves, 2) > float(rng.normal() + 2.0)
+            m2 = _scalar(rng, leaves, 2) <= float(rng.normal() + 3.0)
+            q = q.select(m1, m2) if rng.random() < 0.5 else q.select(np.logical_or(m1, m2))
+        plan = lowering.plan_for(q)
+        if plan is None:                                 # more live values than registers: host path, nothing to compare
+            continue
+        for chunk in st.chunks():
+            with np.errstate(all="ignore"):
+                want = host_chunk(q, chunk)
+                got, _ = lowering.run_reference(plan, st.sample_pairs_level(chunk))
+            assert got.shape == want.shape
+            assert np.array_equal(got, want, equal_nan=True), (seed, np.nanmax(np.abs(got - want)))
