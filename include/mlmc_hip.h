@@ -207,6 +207,19 @@ int mlmc_expr_kernel_time(mlmc_expr *e, double *ms, int64_t *launches, int64_t *
 int mlmc_subsample_gather(const double *fine, const double *coarse, int32_t n_rows, int64_t n, int64_t k, uint64_t seed,
                           double *fine_out, double *coarse_out);
 
+/* ---- synthetic samples in HBM (mlmc/sim/synth_simulation.py:37-46,75-131; seeding mlmc/sampling_pool.py:75-84; sample
+ * ids mlmc/sampler.py:120) -------------------------------------------------------------------------------------------
+ * Samples first_sample .. first_sample + n - 1 of level `level_id` exactly as Sampler + SynthSimulation (distr =
+ * scipy.stats.norm(loc, scale), result_format of synth_simulation.py:136-145: 24 stored rows) produce them: md5 of the sample id
+ * -> MT19937 -> two legacy Box-Muller normals -> x + h sqrt(1e-4 + |x|).  rows (host array): the stored rows wanted
+ * (0..23 = [quantity][time][location][component]); out (host array of DEVICE pointers): one buffer per row in the
+ * storage layout -- interleaved (fine, coarse) pairs [n][2] when coarse_step != 0, else fine only [n] (level 0).
+ * Asynchronous on the library's stream. */
+int mlmc_synth_generate(int32_t level_id, int64_t first_sample, int64_t n, double fine_step, double coarse_step,
+                        double loc, double scale, int32_t n_rows, const int32_t *rows, double *const *out);
+/* seeds_host[i] = SamplingPool.compute_seed("L{level:02d}_S{first + i:07d}") (first uint32 of the md5 digest); synchronous */
+int mlmc_synth_seeds(int32_t level_id, int64_t first_sample, int64_t n, uint32_t *seeds_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -210,12 +210,16 @@ def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache):
     item = _device_cache.get(key) if use_cache else None
     if item is not None:
         return item[0]
-    raw = plan.leaf.samples(chunk_spec)                           # [M_stored, n, 2|1], memoised for this estimate
-    row = np.ascontiguousarray(raw[stored_row], dtype=np.float64)
-    dev = torch.device("cuda", _lib_device())
-    t = torch.from_numpy(row).to(dev)
-    torch.cuda.current_stream(dev).synchronize()        # the library reads it on its own stream
-    _device_cache.uploads += 1
+    storage = getattr(plan.leaf, "_storage", None)
+    if hasattr(storage, "device_row"):                            # samples that already live in HBM (sim/synth_device.py)
+        t = storage.device_row(chunk_spec, stored_row)
+    else:
+        raw = plan.leaf.samples(chunk_spec)                       # [M_stored, n, 2|1], memoised for this estimate
+        row = np.ascontiguousarray(raw[stored_row], dtype=np.float64)
+        dev = torch.device("cuda", _lib_device())
+        t = torch.from_numpy(row).to(dev)
+        torch.cuda.current_stream(dev).synchronize()    # the library reads it on its own stream
+        _device_cache.uploads += 1
     if use_cache:
         _device_cache.put_tensors(key, t, None, owner=plan.leaf)
     return t

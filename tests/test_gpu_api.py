@@ -622,3 +622,39 @@ def test_device_tree_random_trees(hip, seed):
             assert np.array_equal(got, want, equal_nan=True), (seed, np.nanmax(np.abs(got - want)))
             n_checked += 1
     assert n_checked >= 6
+
+
+def test_synth_device_storage_reproduces_reference_golden_means(hip):
+    """The reference's own golden vector (test/test_sampling_pools.py:18: Sampler + SynthSimulation + Estimate, 3 levels x
+    10 samples, norm(1, 2), Legendre(5)) reproduced with samples that never exist on the host: SynthDeviceStorage ->
+    quantity tree -> device estimator.  G7_chain.json holds the reference's full-precision means / vars."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.sim.synth_device import SynthDeviceStorage
+    g7 = json.load(open(os.path.join(GOLDEN, "G7_chain.json")))
+    st = SynthDeviceStorage([[0.01], [0.001], [0.0001]], [10, 10, 10], loc=1.0, scale=2.0)
+    root = make_root_quantity(st, st.load_result_format())
+    q = root['length'][1]['10'][0]
+    qe.device_cache_clear()
+    u0 = qe._device_cache.uploads
+    est = Estimate(q, st, Legendre(5, tuple(g7["domain"])))
+    means, variances = est.estimate_moments()
+    assert qe._device_cache.uploads == u0                                  # nothing came from the host
+    assert np.allclose(means, g7["ref_means_test_sampling_pools_py_18"], atol=1e-5)
+    assert close(means, g7["means"], scale=1.0) and close(variances, g7["vars"], scale=np.max(g7["vars"]))
+    # the host view of the same storage feeds the host-evaluated tree to the same numbers
+    os.environ["MLMC_HIP_DEVICE_TREE"] = "0"
+    try:
+        qe.device_cache_clear()
+        m2, v2 = Estimate(q, st, Legendre(5, tuple(g7["domain"]))).estimate_moments()
+    finally:
+        os.environ.pop("MLMC_HIP_DEVICE_TREE", None)
+        qe.device_cache_clear()
+    assert close(m2, means, scale=1.0) and close(v2, variances, scale=np.max(variances))
+    # chunked generation gives the same samples as one chunk (sample index = position in the level)
+    big = SynthDeviceStorage([[0.5], [0.1]], [5000, 3000], chunk_size=1024)
+    one = SynthDeviceStorage([[0.5], [0.1]], [5000, 3000])
+    a = np.concatenate([big.sample_pairs_level(c) for c in big.chunks(level_id=1)], axis=1)
+    assert np.array_equal(a, one.sample_pairs_level(next(one.chunks(level_id=1))))

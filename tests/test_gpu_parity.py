@@ -615,3 +615,49 @@ def test_log_transform_and_other_families_accumulate(hip):
     b = onp.Basis(onp.LEGENDRE, 10, dom)
     ref = onp.estimate_mean(to_chunks(lv3), lambda v: onp.covariance_rows(b, v))
     _check_against(n, n_rm, s, sp, ref)
+
+
+def test_synth_generation_matches_the_reference_chain(hip):
+    """mlmc_synth_generate against (a) the reference's own outputs in G7_chain.json (sample ids -> md5 seeds ->
+    SynthSimulation.calculate, 3 levels x 10 samples x 24 rows, written by oracle/gen_golden.py from the imported
+    reference) and (b) NumPy's RandomState -- the third-party generator the reference calls -- for 10^5 more samples.
+    Seeds (integer work) must be bit-exact; sample values are bit-exact wherever the device log() and glibc's log()
+    round alike, otherwise 1 ulp apart."""
+    import hashlib
+    import json
+    from mlmc_amd.sim import synth_device as sd
+    g7 = json.load(open(os.path.join(GOLDEN, "G7_chain.json")))
+    steps = [0.01, 0.001, 0.0001]
+    for l, lv in enumerate(g7["levels"]):
+        seeds = sd.sample_seeds(l, 0, 10)
+        assert seeds.tolist() == lv["seeds"]
+        rows = sd.generate_rows(l, 0, 10, steps[l], steps[l - 1] if l else 0.0, list(range(24)), loc=1.0, scale=2.0)
+        hip.check(hip.lib().mlmc_synchronize())
+        got = np.stack([t.cpu().numpy() for t in rows])                      # [24, 10, 2|1]
+        fine, coarse = np.array(lv["fine"]).T, np.array(lv["coarse"]).T      # [24, 10]
+        assert np.allclose(got[:, :, 0], fine, rtol=4e-16, atol=0) and np.mean(got[:, :, 0] == fine) > 0.9
+        if l:
+            assert np.allclose(got[:, :, 1], coarse, rtol=4e-16, atol=0)
+        else:
+            assert got.shape[2] == 1 and not np.any(coarse)
+    # sample ids beyond 7 digits and other levels: seeds against hashlib
+    for level, first in ((0, 9_999_995), (7, 123), (12, 99_999_990)):
+        seeds = sd.sample_seeds(level, first, 12)
+        want = [int(np.frombuffer(hashlib.md5("L{:02d}_S{:07d}".format(level, first + i).encode("ascii")).digest(), dtype="uint32")[0])
+                for i in range(12)]
+        assert seeds.tolist() == want
+    # 10^5 samples against numpy.random.RandomState (legacy seeding + legacy_gauss)
+    n, level, h_f, h_c = 100_000, 3, 0.02, 0.1
+    rows = sd.generate_rows(level, 0, n, h_f, h_c, [0, 1, 3])
+    hip.check(hip.lib().mlmc_synchronize())
+    got = np.stack([t.cpu().numpy() for t in rows])
+    seeds = sd.sample_seeds(level, 0, n)
+    y = np.array([np.random.RandomState(int(s)).standard_normal(2) for s in seeds])          # [n, 2]
+    fn = lambda x, h: x + h * np.sqrt(1e-4 + np.abs(x))
+    want = np.stack([np.stack([fn(y[:, 0], h_f), fn(y[:, 0], h_c)], axis=1),
+                     np.stack([fn(y[:, 1], h_f), fn(y[:, 1], h_c)], axis=1),
+                     np.stack([fn(y[:, 1], h_f) + 1, fn(y[:, 1], h_c) + 1], axis=1)])
+    exact = np.mean(got == want)
+    # a 1-ulp difference of the normal (|y| < 8) is at most 8.9e-16 in absolute terms, also after x + h sqrt(1e-4 + |x|)
+    assert np.max(np.abs(got - want)) < 2e-15, np.max(np.abs(got - want))
+    assert exact > 0.99, exact
