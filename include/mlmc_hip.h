@@ -175,9 +175,13 @@ enum {
     MLMC_X_AND, MLMC_X_OR, MLMC_X_NOT, MLMC_X_XOR,                        /* on flags */
     MLMC_X_N_OPS
 };
+/* flags or-ed into `op` of an arithmetic (ADD..FMOD) or comparison instruction: the operand is `imm`, not a register */
+#define MLMC_X_IMM_A 0x4000
+#define MLMC_X_IMM_B 0x8000
+#define MLMC_X_OP_MASK 0x3fff
 typedef struct {
     uint16_t op, dst, a, b;   /* registers < n_regs; LOAD: a = input row; STORE: b = output row */
-    double imm;
+    double imm;               /* CONST value, or the immediate operand */
 } mlmc_expr_instr;
 #define MLMC_EXPR_MAX_REGS 16
 #define MLMC_EXPR_MAX_INSTR 4096

@@ -69,12 +69,13 @@ __device__ __forceinline__ double np_sign(double a) { return a != a ? a : (a > 0
 // Register file in LDS: [reg][side][slot][thread]; a thread works on S samples (slots) per instruction so that the
 // decode of an instruction and the latency of its loads are shared by S samples.
 template <bool PAIR, int S, bool HEAVY>
-__device__ __forceinline__ void binary(int op, double *d, const double *x, const double *y) {   // d may alias x or y
+__device__ __forceinline__ void binary(int op, double *d, const double *x, const double *y, bool imm_a, bool imm_b,
+                                       double imm) {   // d may alias x or y; an immediate operand replaces a register read
     constexpr int V = (PAIR ? 2 : 1) * S;
     double r[V];
 #pragma unroll
     for (int s = 0; s < V; ++s) {
-        const double a = x[s * X_THREADS], b = y[s * X_THREADS];
+        const double a = imm_a ? imm : x[s * X_THREADS], b = imm_b ? imm : y[s * X_THREADS];
         switch (op) {
             case MLMC_X_ADD: r[s] = a + b; break;
             case MLMC_X_SUB: r[s] = a - b; break;
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__res
         double *const d = mine + (size_t)ins.dst * REG_STRIDE;
         const double *const x = mine + (size_t)ins.a * REG_STRIDE;
         const double *const y = mine + (size_t)ins.b * REG_STRIDE;
-        const int op = ins.op;
+        const int op = ins.op & MLMC_X_OP_MASK;
+        const bool imm_a = (ins.op & MLMC_X_IMM_A) != 0, imm_b = (ins.op & MLMC_X_IMM_B) != 0;
         if (op == MLMC_X_LOAD) {
             const double *__restrict__ row = rows ? rows[ins.a] : tab.p[ins.a];
             if (PAIR) {
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__res
             double v[S];
 #pragma unroll
             for (int k = 0; k < S; ++k) {
-                bool r = compare(op, x[k * X_THREADS], y[k * X_THREADS]);
-                if (PAIR) r = compare(op, x[(S + k) * X_THREADS], y[(S + k) * X_THREADS]) && r;
+                bool r = compare(op, imm_a ? ins.imm : x[k * X_THREADS], imm_b ? ins.imm : y[k * X_THREADS]);
+                if (PAIR) r = compare(op, imm_a ? ins.imm : x[(S + k) * X_THREADS], imm_b ? ins.imm : y[(S + k) * X_THREADS]) && r;
                 v[k] = r ? 1.0 : 0.0;
             }
 #pragma unroll
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__res
                 if (PAIR) d[(S + k) * X_THREADS] = v[k];
             }
         } else if ((op >= MLMC_X_ADD && op <= MLMC_X_FMOD) || op == MLMC_X_AND || op == MLMC_X_OR || op == MLMC_X_XOR) {
-            binary<PAIR, S, HEAVY>(op, d, x, y);
+            binary<PAIR, S, HEAVY>(op, d, x, y, imm_a, imm_b, ins.imm);
         } else {
             unary<PAIR, S, HEAVY>(op, d, x);
         }
@@ -326,11 +328,15 @@ int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_reg
     bool selects = false, heavy = false;
     std::vector<char> written(n_regs, 0), stored(n_out_rows, 0);
     for (int k = 0; k < n_instr; ++k) {   // validate: the kernel trusts every index
-        const mlmc_expr_instr &in = prog[k];
+        mlmc_expr_instr in = prog[k];
+        const bool imm_a = (in.op & MLMC_X_IMM_A) != 0, imm_b = (in.op & MLMC_X_IMM_B) != 0;
+        in.op &= MLMC_X_OP_MASK;
         if (in.op >= MLMC_X_N_OPS) return fail("mlmc_expr_create: unknown opcode");
-        const bool reads_a = in.op != MLMC_X_LOAD && in.op != MLMC_X_CONST;
-        const bool reads_b = (in.op >= MLMC_X_ADD && in.op <= MLMC_X_FMOD) || (in.op >= MLMC_X_LT && in.op <= MLMC_X_NE) ||
-                             in.op == MLMC_X_AND || in.op == MLMC_X_OR || in.op == MLMC_X_XOR;
+        const bool two_operands = (in.op >= MLMC_X_ADD && in.op <= MLMC_X_FMOD) || (in.op >= MLMC_X_LT && in.op <= MLMC_X_NE);
+        if ((imm_a || imm_b) && (!two_operands || (imm_a && imm_b)))
+            return fail("mlmc_expr_create: immediate operands are for arithmetic / comparison instructions, one per instruction");
+        const bool reads_a = in.op != MLMC_X_LOAD && in.op != MLMC_X_CONST && !imm_a;
+        const bool reads_b = (two_operands || in.op == MLMC_X_AND || in.op == MLMC_X_OR || in.op == MLMC_X_XOR) && !imm_b;
         const bool writes = in.op != MLMC_X_STORE && in.op != MLMC_X_SELECT;
         if (in.op == MLMC_X_LOAD && in.a >= n_in_rows) return fail("mlmc_expr_create: input row out of range");
         if (reads_a && (in.a >= n_regs || !written[in.a])) return fail("mlmc_expr_create: operand a reads an unset register");

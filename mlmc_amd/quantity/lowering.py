@@ -31,6 +31,9 @@ _OP_NAMES = ["LOAD", "CONST", "STORE", "SELECT", "ADD", "SUB", "MUL", "DIV", "MO
 OP = {name: i for i, name in enumerate(_OP_NAMES)}
 MAX_REGS = 16
 MAX_INSTR = 4096
+IMM_A, IMM_B, OP_MASK = 0x4000, 0x8000, 0x3fff      # operand-is-immediate flags of include/mlmc_hip.h
+_IMM_OK = {"ADD", "SUB", "MUL", "DIV", "MOD", "POW", "MAXIMUM", "MINIMUM", "FMAX", "FMIN", "ATAN2", "HYPOT", "FMOD",
+           "LT", "LE", "GT", "GE", "EQ", "NE"}
 
 _BINOPS = {operator.add: "ADD", operator.sub: "SUB", operator.mul: "MUL", operator.truediv: "DIV", operator.mod: "MOD"}
 _CMPOPS = {operator.lt: "LT", operator.le: "LE", operator.gt: "GT", operator.ge: "GE", operator.eq: "EQ", operator.ne: "NE"}
@@ -217,14 +220,27 @@ def _schedule(bld, out_rows):
     order = []            # ("val", v) | ("store", v, row) | ("select", v)
     done = set()
 
+    def is_const(v):
+        return v >= 0 and bld.nodes[v][0] == "CONST"
+
+    def imm_form(x):
+        """(register operand a, register operand b, flags, imm) of value x when one operand can ride as an immediate."""
+        op, a, b, _ = bld.nodes[x]
+        if op in _IMM_OK:
+            if is_const(b) and not is_const(a):
+                return a, -1, IMM_B, bld.nodes[b][3]
+            if is_const(a) and not is_const(b):
+                return -1, b, IMM_A, bld.nodes[a][3]
+        return a, b, 0, 0.0
+
     def emit(v):
         stack = [(v, False)]
         while stack:
             x, expanded = stack.pop()
             if x in done:
                 continue
-            op, a, b, _ = bld.nodes[x]
-            deps = [d for d in ((a, b) if op not in ("LOAD", "CONST") else ()) if d >= 0]
+            op = bld.nodes[x][0]
+            deps = [d for d in (imm_form(x)[:2] if op not in ("LOAD", "CONST") else ()) if d >= 0]
             if expanded or not deps:
                 done.add(x)
                 order.append(("val", x))
@@ -244,9 +260,9 @@ def _schedule(bld, out_rows):
     last_use = {}
     for pos, item in enumerate(order):
         if item[0] == "val":
-            op, a, b, _ = bld.nodes[item[1]]
+            op = bld.nodes[item[1]][0]
             if op not in ("LOAD", "CONST"):
-                for d in (a, b):
+                for d in imm_form(item[1])[:2]:
                     if d >= 0:
                         last_use[d] = pos
         else:
@@ -259,12 +275,16 @@ def _schedule(bld, out_rows):
         if item[0] == "val":
             v = item[1]
             op, a, b, imm = bld.nodes[v]
+            flags = 0
             if op == "LOAD":
                 ra, rb = a, 0
             elif op == "CONST":
                 ra, rb = 0, 0
             else:
-                ra, rb = reg[a], (reg[b] if b >= 0 else 0)
+                a, b, flags, imm_value = imm_form(v)
+                if flags:
+                    imm = imm_value
+                ra, rb = (reg[a] if a >= 0 else 0), (reg[b] if b >= 0 else 0)
                 for d in {a, b}:                        # operands that die here free their register for the result
                     if d >= 0 and last_use.get(d) == pos:
                         free.append(reg[d])
@@ -272,7 +292,7 @@ def _schedule(bld, out_rows):
                 raise NotLowerable("more than {} live values".format(MAX_REGS))
             reg[v] = free.pop()
             n_regs = max(n_regs, reg[v] + 1)
-            prog.append((OP[op], reg[v], ra, rb, imm))
+            prog.append((OP[op] | flags, reg[v], ra, rb, imm))
             if v not in last_use:                        # never read (cannot happen for scheduled values, but be safe)
                 free.append(reg[v])
         else:
@@ -392,7 +412,10 @@ def run_reference(plan, stored, has_coarse=True):
     inv = {v: k for k, v in OP.items()}
     with np.errstate(all="ignore"):
         for op, dst, a, b, imm in plan.prog:
-            name = inv[op]
+            name = inv[op & OP_MASK]
+            if op & (IMM_A | IMM_B):                      # the immediate stands in for a register
+                regs[-1] = np.full((n, s), imm)
+                a, b = (-1, b) if op & IMM_A else (a, -1)
             if name == "LOAD":
                 regs[dst] = stored[plan.in_rows[a]].astype(np.float64)
             elif name == "CONST":
