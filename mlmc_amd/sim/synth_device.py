@@ -57,13 +57,18 @@ def generate_rows(level_id, first_sample, n, fine_step, coarse_step, rows, devic
 class SynthDeviceStorage(SampleStorage):
     """Read-only storage of SynthSimulation samples that live (only) in HBM."""
 
-    def __init__(self, level_steps, n_samples, chunk_size=None, complexity=2, loc=0.0, scale=1.0):
+    def __init__(self, level_steps, n_samples, chunk_size=None, complexity=2, loc=0.0, scale=1.0, shard=None):
         """level_steps: fine simulation step of every level (e.g. estimator.determine_level_parameters);
         n_samples: collected samples per level; chunk_size: samples per chunk (None: one chunk per level);
-        loc, scale: the distribution scipy.stats.norm(loc, scale) of SynthSimulation's config."""
+        loc, scale: the distribution scipy.stats.norm(loc, scale) of SynthSimulation's config;
+        shard: (rank, world_size) -- this process owns the contiguous slice engine.shard_bounds of every level
+        (multi-GPU estimates: one process per GPU, the level sums are all-reduced by estimate_mean)."""
+        from ..engine import shard_bounds
         self._loc, self._scale = float(loc), float(scale)
         self._steps = [float(np.ravel(s)[0]) for s in level_steps]
-        self._n = [int(v) for v in n_samples]
+        bounds = [shard_bounds(int(v), *shard) if shard is not None else (0, int(v)) for v in n_samples]
+        self._first = [lo for lo, _ in bounds]             # sample index of the first owned sample of every level
+        self._n = [hi - lo for lo, hi in bounds]
         assert len(self._steps) == len(self._n)
         self._chunk_size = chunk_size
         self._n_ops = [n_ops_estimate(h, complexity) for h in self._steps]
@@ -107,14 +112,16 @@ class SynthDeviceStorage(SampleStorage):
         level = int(chunk_spec.level_id)
         sl = chunk_spec.chunk_slice if chunk_spec.chunk_slice is not None else slice(0, self._n[level], 1)
         h_f, h_c = self._steps_of(level)
-        return generate_rows(level, sl.start, sl.stop - sl.start, h_f, h_c, [stored_row], loc=self._loc, scale=self._scale)[0]
+        return generate_rows(level, self._first[level] + sl.start, sl.stop - sl.start, h_f, h_c, [stored_row], loc=self._loc,
+                             scale=self._scale)[0]
 
     def sample_pairs_level(self, chunk_spec):
         """Host copy [24, n, 2|1] of a chunk (small chunks / tests; the estimators use device_row)."""
         level = int(chunk_spec.level_id)
         sl = chunk_spec.chunk_slice if chunk_spec.chunk_slice is not None else slice(0, self._n[level], 1)
         h_f, h_c = self._steps_of(level)
-        rows = generate_rows(level, sl.start, sl.stop - sl.start, h_f, h_c, list(range(N_ROWS)), loc=self._loc, scale=self._scale)
+        rows = generate_rows(level, self._first[level] + sl.start, sl.stop - sl.start, h_f, h_c, list(range(N_ROWS)), loc=self._loc,
+                             scale=self._scale)
         _lib.check(_lib.lib().mlmc_synchronize())
         return np.stack([t.cpu().numpy() for t in rows])
 

@@ -524,6 +524,55 @@ def test_two_rank_sharded_estimate_on_gpu(hip, tmp_path):
         assert close(r0["s"], s, scale, 1e-12) and close(r0["sp"], sp, None, 1e-12)
 
 
+def _sharded_api_worker(rank, world, port, n_total, steps, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from mlmc_amd import _lib, Legendre
+        from mlmc_amd.estimator import Estimate
+        from mlmc_amd.quantity.quantity import make_root_quantity
+        from mlmc_amd.sim.synth_device import SynthDeviceStorage
+        _lib.init(0)
+        st = SynthDeviceStorage(steps, n_total, shard=(rank, world), chunk_size=20000)
+        root = make_root_quantity(st, st.load_result_format())
+        q = (root['length'][1]['10'][0] - 0.25) * root['width'][2]['40'][1]
+        est = Estimate(q, st, Legendre(8, (-12.0, 20.0)))
+        means, variances = est.estimate_moments()
+        cov, _ = est.estimate_covariance()
+        np.savez(os.path.join(out_dir, f"api_rank{rank}.npz"), means=means, variances=variances, cov=cov)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_estimate_through_the_python_api(hip, tmp_path):
+    """Whole Python path with two ranks (gloo transport, one GPU): every rank generates ITS shard of the synthetic levels
+    in HBM (SynthDeviceStorage(shard=...)), evaluates the quantity tree on the device, and Estimate all-reduces the level
+    sums; both ranks end with the estimate one process computes over all samples."""
+    import socket
+    import torch.multiprocessing as mp
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.sim.synth_device import SynthDeviceStorage
+    n_total, steps = [70001, 40000, 21111], [[0.5], [0.1], [0.02]]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_sharded_api_worker, args=(2, port, n_total, steps, str(tmp_path)), nprocs=2, join=True)
+    st = SynthDeviceStorage(steps, n_total)
+    root = make_root_quantity(st, st.load_result_format())
+    q = (root['length'][1]['10'][0] - 0.25) * root['width'][2]['40'][1]
+    est = Estimate(q, st, Legendre(8, (-12.0, 20.0)))
+    means, variances = est.estimate_moments()
+    cov, _ = est.estimate_covariance()
+    r0, r1 = np.load(tmp_path / "api_rank0.npz"), np.load(tmp_path / "api_rank1.npz")
+    for k in ("means", "variances", "cov"):
+        assert np.array_equal(r0[k], r1[k])
+    assert close(r0["means"], means, 1.0, 1e-12) and close(r0["variances"], variances, np.max(variances), 1e-12)
+    assert close(r0["cov"], cov, 1.0, 1e-12)
+
+
 def test_spline_moments(hip):
     """Cubic B-spline moments -- NOT in the reference ("parity unpinned"): device evaluation and estimates
     against scipy.interpolate.BSpline through the oracle."""
