@@ -132,7 +132,9 @@ class Estimate:
         self.var_bs_var = np.var(bs_var, axis=0, ddof=1)
         self.var_bs_l_means = np.var(bs_l_means, axis=0, ddof=1)
         self.var_bs_l_vars = np.var(bs_l_vars, axis=0, ddof=1)
-        self._bs_level_mean_variance = self.var_bs_l_means * np.array(self._sample_storage.get_n_collected())[:, None]
+        n_coll = np.array(self._sample_storage.get_n_collected())
+        # [L, R] for scalar quantities (reference: `[:, None]`); array-typed quantities carry extra trailing axes
+        self._bs_level_mean_variance = self.var_bs_l_means * n_coll.reshape((-1,) + (1,) * (self.var_bs_l_means.ndim - 1))
 
     def bs_target_var_n_estimated(self, target_var, sample_vec=None):
         sample_vec = determine_sample_vec(n_collected_samples=self._sample_storage.get_n_collected(),

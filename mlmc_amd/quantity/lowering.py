@@ -319,6 +319,8 @@ class DevicePlan:
         self.n_regs = int(n_regs)
         self.selects = bool(selects)
         self._handle = None
+        # two trees with the same program over the same stored rows compute the same rows: cache identity
+        self.signature = (tuple(self.prog), tuple(self.in_rows))
 
     def instr_array(self):
         arr = (ExprInstr * len(self.prog))()

@@ -206,11 +206,12 @@ def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache):
     """One stored row of one chunk as a device tensor in the storage's own layout: interleaved (fine, coarse) pairs
     [n, 2], or [n, 1] at level 0.  Uploaded once per (storage, chunk, row) and shared by every quantity that reads it."""
     import torch
-    key = ("row", id(plan.leaf)) + chunk_key + (stored_row,)
+    storage = getattr(plan.leaf, "_storage", None)
+    owner = storage if storage is not None else plan.leaf
+    key = ("row", id(owner)) + chunk_key + (stored_row,)
     item = _device_cache.get(key) if use_cache else None
     if item is not None:
         return item[0]
-    storage = getattr(plan.leaf, "_storage", None)
     if hasattr(storage, "device_row"):                            # samples that already live in HBM (sim/synth_device.py)
         t = storage.device_row(chunk_spec, stored_row)
     else:
@@ -221,7 +222,7 @@ def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache):
         torch.cuda.current_stream(dev).synchronize()    # the library reads it on its own stream
         _device_cache.uploads += 1
     if use_cache:
-        _device_cache.put_tensors(key, t, None, owner=plan.leaf)
+        _device_cache.put_tensors(key, t, None, owner=owner)
     return t
 
 
@@ -240,7 +241,13 @@ def _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache):
     torch CUDA tensors (resident: served from / added to the HBM cache) or, when the chunk does not fit the cache budget
     and the tree is evaluated on the host, as NumPy arrays that go through the staging buffer of the C ABI."""
     sl = chunk_spec.chunk_slice
-    key = (id(source), chunk_spec.level_id, chunk_spec.chunk_id, None if sl is None else (sl.start, sl.stop),
+    if plan is not None:
+        # equivalent trees (rebuilt quantity objects, a second make_root_quantity over the same storage) share entries
+        owner = getattr(plan.leaf, "_storage", plan.leaf)
+        ident = (id(owner), plan.signature)
+    else:
+        owner, ident = source, id(source)
+    key = (ident, chunk_spec.level_id, chunk_spec.chunk_id, None if sl is None else (sl.start, sl.stop),
            None if n_collected is None else n_collected[int(chunk_spec.level_id)])
     item = _device_cache.get(key) if use_cache else None
     if item is not None:
@@ -251,7 +258,7 @@ def _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache):
             import torch
             return torch.empty((plan.n_out, 0), dtype=torch.float64), None
         if use_cache:
-            _device_cache.put_tensors(key, got[0], got[1], owner=source)
+            _device_cache.put_tensors(key, got[0], got[1], owner=owner)
         return got
     raw = source.samples(chunk_spec)                             # [M, n, 2|1], host evaluation of the tree
     if raw.shape[1] == 0:
