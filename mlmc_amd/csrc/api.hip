@@ -244,7 +244,7 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
         a->int_width = 3 * (int64_t)a->RP * a->RP;
     }
     const size_t tot = (size_t)n_levels * n_comp * a->int_width;
-    a->state_bytes = sizeof(double) * tot + sizeof(int64_t) * 2 * n_levels + 64;
+    a->state_bytes = sizeof(double) * tot + sizeof(int64_t) * 2 * n_levels;
     a->out_bytes = (sizeof(int64_t) + sizeof(double)) * 2 * n_levels + 2 * sizeof(double) * (size_t)n_levels * a->K;
     if (hipMalloc(&a->d_state, a->state_bytes) != hipSuccess || hipMalloc(&a->d_out, a->out_bytes) != hipSuccess ||
         hipHostMalloc(&a->h_out, a->out_bytes, hipHostMallocDefault) != hipSuccess) {
@@ -253,7 +253,6 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     }
     a->d_totals = (double *)a->d_state;
     a->d_counts = (int64_t *)(a->d_totals + tot);
-    a->d_ticket = (unsigned *)(a->d_counts + 2 * (size_t)n_levels);
     a->level_flushed.assign(n_levels, 0);
     if (mode == MLMC_MODE_MOMENTS && n_comp == 1 && b->out_size == 0) {
         void *dev_view = nullptr;
@@ -324,7 +323,9 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             MLMC_HIP_CHECK(hipMemcpyAsync(a->d_stage_c, coarse, bytes, hipMemcpyHostToDevice, st));
             d_c = a->d_stage_c;
         }
-        // pageable host memory: the copies above have been staged by the runtime when they return
+        // the caller may reuse its buffers as soon as push returns: pageable memory has been staged by the runtime at
+        // this point, pinned memory has not -- wait for the copies (the kernels below still run asynchronously)
+        MLMC_HIP_CHECK(hipStreamSynchronize(st));
     } else if (mem_kind != MLMC_DEVICE) {
         return fail("mlmc_accum_push: bad mem_kind");
     }

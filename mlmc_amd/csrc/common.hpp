@@ -70,11 +70,10 @@ struct mlmc_accum {
     // internal totals per (level, component): MOMENTS: [2][R] (sum d, sum d^2) (+ [R][R] diff Gram if transform)
     //                                         COV: [3][RP][RP] (G0, G1, G2)
     int64_t int_width = 0;        // doubles per (level, comp)
-    void *d_state = nullptr;      // one allocation: totals | counts | ticket (reset = one memset)
+    void *d_state = nullptr;      // one allocation: totals | counts (reset = one memset)
     size_t state_bytes = 0;
     double *d_totals = nullptr;   // [n_levels][n_comp][int_width]
     int64_t *d_counts = nullptr;  // [n_levels][2]  (kept, removed)
-    unsigned *d_ticket = nullptr; // arrival counter of the in-kernel grid reduction
     // scratch
     double *d_partials = nullptr; size_t partials_cap = 0;
     int64_t *d_pcounts = nullptr; size_t pcounts_cap = 0;

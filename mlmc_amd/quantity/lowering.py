@@ -321,6 +321,9 @@ class DevicePlan:
         self._handle = None
         # two trees with the same program over the same stored rows compute the same rows: cache identity
         self.signature = (tuple(self.prog), tuple(self.in_rows))
+        # the tree only picks one stored row (the usual scalar quantity root[name][time][location][i])
+        self.is_row_copy = (len(self.prog) == 2 and self.prog[0][0] == OP["LOAD"] and self.prog[1][0] == OP["STORE"]
+                            and self.n_out == 1)
 
     def instr_array(self):
         arr = (ExprInstr * len(self.prog))()

@@ -232,6 +232,8 @@ def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache):
     n, width = rows[0].shape
     if n == 0:
         return None
+    if width == 1 and plan.is_row_copy:
+        return rows[0].view(1, n), None         # a level-0 row already is the contiguous fine array: no kernel, no copy
     fine, coarse, _ = plan.evaluate(rows, has_coarse=(width == 2), n=n)
     return fine, coarse
 
