@@ -433,6 +433,16 @@ int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind) {
     if (need_runtime()) return 1;
     if (!a || !packed) return fail("mlmc_accum_finalize_packed: null argument");
     hipStream_t st = rt().stream;
+    if (a->mode == MLMC_MODE_MOMENTS && a->host_outputs && mem_kind == MLMC_DEVICE && a->R <= MAX_TERMS_PER_PASS &&
+        (int)a->pending.size() == a->n_levels &&
+        std::none_of(a->level_flushed.begin(), a->level_flushed.end(), [](char f) { return f != 0; })) {
+        // the whole estimate is pending as one launch: its grid reduction writes the packed buffer directly
+        // (every level is covered, so no finalize kernel and no device-to-device copy are needed)
+        a->packed_target = packed;
+        const int rcf = flush_moments(a);
+        a->packed_target = nullptr;
+        return rcf;
+    }
     if (a->mode == MLMC_MODE_MOMENTS)
         if (int rcf = flush_moments(a)) return rcf;
     int rc = (a->mode == MLMC_MODE_MOMENTS) ? launch_moments_finalize(a) : launch_cov_finalize(a);

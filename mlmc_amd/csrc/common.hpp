@@ -85,6 +85,7 @@ struct mlmc_accum {
     void *h_out = nullptr;        // pinned host mirror of d_out (device-mapped)
     // MOMENTS with a plain basis and one component: k_reduce_partials writes the finished rows straight into h_out
     bool host_outputs = false;
+    double *packed_target = nullptr;   // set for the duration of a flush started by mlmc_accum_finalize_packed(MLMC_DEVICE)
     double *h_out_s = nullptr, *h_out_sp = nullptr; int64_t *h_out_n = nullptr;   // device-side addresses of h_out's parts
     std::vector<char> level_flushed;   // levels whose rows in h_out are current (set by flush_moments, cleared by reset)
     double *d_out_s = nullptr, *d_out_sp = nullptr, *d_out_nd = nullptr; int64_t *d_out_n = nullptr;

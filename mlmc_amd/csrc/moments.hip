@@ -152,6 +152,8 @@ struct ReduceTarget {
     // total also writes the caller-visible value, so finalize needs neither a finalize kernel nor a D2H copy
     double *h_s, *h_sp;            // [R] rows of this level in the pinned mirror; nullptr: not used
     int64_t *h_n;                  // &n[level]; n_rm[level] is h_n[h_n_stride]
+    double *p_nd;                  // optional second copy for the packed all-reduce buffer: counts as doubles,
+    double *p_s, *p_sp;            //   rows of this level (device memory of the caller); nullptr: not used
     const double *scale;           // P_i = scale[i] * Q_i
     int64_t h_n_stride;
 };
@@ -336,6 +338,10 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restri
                     const double c = tg.scale[term];
                     if (which == 0) tg.h_s[term] = c * t;
                     else tg.h_sp[term] = (c * c) * t;
+                    if (tg.p_s) {
+                        if (which == 0) tg.p_s[term] = c * t;
+                        else tg.p_sp[term] = (c * c) * t;
+                    }
                 }
             }
         }
@@ -350,6 +356,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restri
             tg.counts[0] = a;
             tg.counts[1] = b;
             if (tg.h_n) { tg.h_n[0] = a; tg.h_n[tg.h_n_stride] = b; }
+            if (tg.p_nd) { tg.p_nd[0] = (double)a; tg.p_nd[tg.h_n_stride] = (double)b; }   // exact below 2^53
         }
     }
 }
@@ -568,6 +575,12 @@ int flush_moments(mlmc_accum *a) {
                 rtab.t[k].h_sp = a->h_out_sp + (int64_t)p.level * R;
                 rtab.t[k].h_n = a->h_out_n + p.level;
                 rtab.t[k].h_n_stride = a->n_levels;
+                if (a->packed_target) {   // mlmc_accum_finalize_packed(MLMC_DEVICE): n | n_rm | s | sp as doubles
+                    double *pk = a->packed_target;
+                    rtab.t[k].p_nd = pk + p.level;
+                    rtab.t[k].p_s = pk + 2 * (int64_t)a->n_levels + (int64_t)p.level * R;
+                    rtab.t[k].p_sp = rtab.t[k].p_s + (int64_t)a->n_levels * R;
+                }
                 rtab.t[k].scale = a->basis->d_scale;
                 a->level_flushed[p.level] = 1;
             }

@@ -143,9 +143,27 @@ def allreduce_partials(packed, group=None):
     """The only exchange step of the path: ONE all-reduce (sum) of the packed fp64 partials
     [n(L) | n_rm(L) | s(L*K) | sp(L*K)] over the ranks (RCCL over xGMI with backend "nccl"; "gloo" in CPU tests).
     The sample counts travel as doubles (exact below 2^53).  Takes a torch tensor, returns a NumPy array."""
+    import torch
     import torch.distributed as dist
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-    return packed.cpu().numpy()
+    if not packed.is_cuda:
+        return packed.numpy()
+    host = _pinned_like(packed)                         # one pinned landing buffer per size, reused
+    host.copy_(packed, non_blocking=True)
+    torch.cuda.current_stream(packed.device).synchronize()
+    return host.numpy().copy()
+
+
+_pinned = {}
+
+
+def _pinned_like(t):
+    import torch
+    buf = _pinned.get(t.numel())
+    if buf is None:
+        buf = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+        _pinned[t.numel()] = buf
+    return buf
 
 
 def unpack_partials(packed, L, K):
