@@ -423,10 +423,37 @@ def g7_chain():
     print("G7 means", means)
 
 
+def g8_quantity_tree():
+    """Chunks of derived quantities evaluated by the reference's Quantity tree (mlmc/quantity/quantity.py: arithmetic,
+    ufuncs, comparisons, select, indexing, time interpolation, QArray) on a seeded 3-level storage of the SynthSimulation
+    result format.  The trees are tests/zoo.py::expression_zoo built from the reference's objects; inputs are
+    regenerated by tests/zoo.py::level_data(n, seed), outputs land in G8_quantity_tree.npz."""
+    sys.path.insert(0, os.path.dirname(OUT))                       # tests/
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))      # repo root
+    import zoo
+    import mlmc.quantity.quantity as q
+    from mlmc.quantity.quantity_spec import QuantitySpec
+    n, seed = (60, 45, 30), 11
+    fmt = zoo.result_format(QuantitySpec)
+    arrs = []
+    for fine, coarse in zoo.level_data(n, seed):
+        arrs.append(np.stack([fine, np.zeros_like(fine) if coarse is None else coarse], axis=1))     # [N, 2, M]
+    st = make_storage(arrs, [[0.5], [0.1], [0.02]], [1.0, 2.0, 3.0], fmt)
+    root = q.make_root_quantity(st, fmt)
+    trees = zoo.expression_zoo(root, q.Quantity)
+    out = {"n": np.array(n), "seed": np.array(seed)}
+    with np.errstate(all="ignore"):
+        for name, tree in trees.items():
+            for chunk in st.chunks():
+                out["{}__L{}".format(name, chunk.level_id)] = np.asarray(tree.samples(chunk), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "G8_quantity_tree.npz"), **out)
+    print("G8", len(out) - 2, "chunks of", len(trees), "trees")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     _install_shims()
-    which = sys.argv[1:] or ["g1", "g2", "g5", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g5", "g7", "g8"]
     if "g1" in which:
         g1_basis()
     if "g2" in which:
@@ -435,3 +462,5 @@ if __name__ == "__main__":
         g5_g6()
     if "g7" in which:
         g7_chain()
+    if "g8" in which:
+        g8_quantity_tree()

@@ -658,3 +658,34 @@ def test_synth_device_storage_reproduces_reference_golden_means(hip):
     one = SynthDeviceStorage([[0.5], [0.1]], [5000, 3000])
     a = np.concatenate([big.sample_pairs_level(c) for c in big.chunks(level_id=1)], axis=1)
     assert np.array_equal(a, one.sample_pairs_level(next(one.chunks(level_id=1))))
+
+
+def test_device_tree_against_reference_golden(hip):
+    """The byte-code kernel against chunks computed by the reference's own Quantity tree (tests/golden/G8_quantity_tree.npz,
+    written by oracle/gen_golden.py from the imported reference): bit-exact for IEEE arithmetic / comparisons / select /
+    interpolation, 1e-13 for the libm-backed ufuncs."""
+    import torch
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from tests.test_lowering import _g8, _spec, expression_zoo, make_storage
+    g8 = _g8()
+    st = make_storage(tuple(int(v) for v in g8["n"]), seed=int(g8["seed"]))
+    root = make_root_quantity(st, _spec())
+    dev = torch.device("cuda", 0)
+    libm = {"ufunc_sin_exp", "ufunc_pow_sqrt", "deep"}
+    for name, q in expression_zoo(root).items():
+        plan = lowering.lower(q)
+        for chunk in st.chunks():
+            want = g8["{}__L{}".format(name, chunk.level_id)]
+            stored = st.sample_pairs_level(chunk)
+            rows = [torch.from_numpy(np.ascontiguousarray(stored[r])).to(dev) for r in plan.in_rows]
+            torch.cuda.synchronize()
+            f, c, _ = plan.evaluate(rows, has_coarse=(stored.shape[-1] == 2), n=stored.shape[1], sync=True)
+            got = f.cpu().numpy()[:, :, None]
+            if c is not None:
+                got = np.concatenate([got, c.cpu().numpy()[:, :, None]], axis=2)
+            assert got.shape == want.shape, (name, got.shape, want.shape)
+            if name in libm:
+                assert np.allclose(got, want, rtol=1e-13, atol=1e-15), (name, np.max(np.abs(got - want)))
+            else:
+                assert np.array_equal(got, want, equal_nan=True), (name, np.nanmax(np.abs(got - want)))

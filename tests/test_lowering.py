@@ -8,61 +8,25 @@ import pytest
 
 def _spec():
     from mlmc_amd.quantity.quantity_spec import QuantitySpec
-    return [QuantitySpec(name="length", unit="m", shape=(2, 1), times=[1, 2, 3], locations=['10', '20']),
-            QuantitySpec(name="width", unit="mm", shape=(2, 1), times=[1, 2, 3], locations=['30', '40'])]
+    from tests.zoo import result_format
+    return result_format(QuantitySpec)
 
 
 def make_storage(n=(700, 500, 300), chunk_size=None, seed=5):
     from mlmc_amd.sample_storage import Memory
-    rng = np.random.default_rng(seed)
+    from tests.zoo import level_data
     st = Memory(chunk_size=chunk_size)
     st.save_global_data(result_format=_spec(), level_parameters=[[0.5], [0.1], [0.02]])
-    M = 24
-    for l, nl in enumerate(n):
-        fine = rng.normal(size=(nl, M)) + 2.0
-        coarse = fine + 0.1 * rng.normal(size=(nl, M)) if l else None
+    for l, (fine, coarse) in enumerate(level_data(n, seed)):
         st.set_level_samples(l, fine, coarse)
     st.save_n_ops([(l, (10.0 * (l + 1) * nl, nl)) for l, nl in enumerate(n)])
     return st
 
 
 def expression_zoo(root):
-    """name -> quantity; the kinds of trees the reference's test/test_quantity_concept.py builds."""
-    length = root['length']
-    width = root['width']
-    loc = length[2]['10']                       # 2 rows
-    x = loc[0]
-    y = width[1]['30'][1]
-    zoo = {
-        "leaf_scalar": x,
-        "leaf_rows": length[3],                 # 4 rows (two locations)
-        "whole_root": root,                     # all 24 rows
-        "add_const": x + 1.5,
-        "radd_rsub": 3.0 - (2.0 + x),
-        "mul_div": (x * y) / (y + 10.0),
-        "mod": (x * 7.0) % 3.0,
-        "rmod_neg": (-5.0) % (x + 4.0),
-        "array_const": loc * np.array([2.0, -1.0]),
-        "rows_plus_scalar": length[1] + x,      # 4 rows broadcast with 1
-        "central": (x - 2.0) * (x - 2.0),
-        "ufunc_sin_exp": np.sin(x) + np.exp(np.negative(y)),
-        "ufunc_binary": np.maximum(x, y) - np.minimum(x, 2.0),
-        "ufunc_pow_sqrt": np.sqrt(np.abs(x)) + np.power(np.abs(y), 1.5),
-        "ufunc_add": np.add(x, y),
-        "interp": length.time_interpolation(2.5)['20'],
-        "interp_edge": width.time_interpolation(1.0),
-        "select_gt": x.select(x > 2.0),
-        "select_two": loc.select(loc < 4.5, y >= 1.0),
-        "select_expr": (x * y).select(np.logical_or(x > 2.5, y < 1.5)),
-        "select_not": x.select(np.logical_not(x > 2.0)),
-        "select_vec_mask": loc.select(loc > 0.5),                      # all rows must pass
-        "eq_ne": x.select(x != y, y == y),
-        "deep": np.log1p(np.abs(np.tanh(x) * np.cos(y) + np.sqrt(np.square(y) + 1.0))) / (1.0 + np.exp2(np.negative(x))),
-        "shared_subexpr": (x + y) * (x + y) + (x + y),
-    }
     from mlmc_amd.quantity.quantity import Quantity
-    zoo["qarray"] = Quantity.QArray([x, y, x + y])
-    return zoo
+    from tests import zoo
+    return zoo.expression_zoo(root, Quantity)
 
 
 def host_chunk(q, chunk):
@@ -204,3 +168,31 @@ def test_random_trees_lower_to_equivalent_programs(seed):
                 got, _ = lowering.run_reference(plan, st.sample_pairs_level(chunk))
             assert got.shape == want.shape
             assert np.array_equal(got, want, equal_nan=True), (seed, np.nanmax(np.abs(got - want)))
+
+
+def _g8():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G8_quantity_tree.npz"))
+
+
+def test_reference_quantity_tree_golden_host_and_program():
+    """G8_quantity_tree.npz: chunks of the zoo's trees evaluated by the REFERENCE's Quantity classes
+    (oracle/gen_golden.py g8).  The host tree of mlmc_amd and the lowered programs (NumPy interpreter) reproduce them bit
+    for bit -- the device kernel is checked against the same file in tests/test_gpu_api.py."""
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    g8 = _g8()
+    st = make_storage(tuple(int(v) for v in g8["n"]), seed=int(g8["seed"]))
+    root = make_root_quantity(st, _spec())
+    n_checked = 0
+    for name, q in expression_zoo(root).items():
+        plan = lowering.lower(q)
+        for chunk in st.chunks():
+            want = g8["{}__L{}".format(name, chunk.level_id)]
+            with np.errstate(all="ignore"):
+                host = host_chunk(q, chunk)
+                prog, _ = lowering.run_reference(plan, st.sample_pairs_level(chunk))
+            assert host.shape == want.shape and np.array_equal(host, want, equal_nan=True), (name, "host tree")
+            assert prog.shape == want.shape and np.array_equal(prog, want, equal_nan=True), (name, "program")
+            n_checked += 1
+    assert n_checked == len(g8.files) - 2
