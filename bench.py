@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: moment-evals/s of one complete MLMC moment estimate on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|5|6]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5|6]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
 (one rank per GPU, RCCL).  Workload at N = 1: BASELINE.json configs[1] -- 3 levels x 10^7 synthetic samples,
@@ -32,6 +32,9 @@ CONFIGS = {
             workload="BASELINE configs[1]: 3 levels x 1e7 synthetic samples per GPU, Legendre n_moments=32, mean+var estimate"),
     3: dict(L=5, n_per_level=10_000_000, R=64, mode="cov",
             workload="BASELINE configs[2]: 5 levels x 1e7 synthetic samples per GPU, Legendre n_moments=64, moment covariance mean+var + level-variance regression + n_samples re-allocation"),
+    4: dict(L=5, n_per_level=12_500_000, R=64, mode="cov",
+            workload="BASELINE configs[3] per-GPU share: 5 levels x 1.25e7 synthetic samples per GPU (1e8 per level over 8 GPUs), "
+                     "Legendre n_moments=64, moment covariance mean+var + level-variance regression + re-allocation as configs[2]; one all-reduce of the [L, 2 + 2 R^2] partial sums per estimate"),
     5: dict(L=1, n_per_level=12_500_000, R=128, mode="moments", basis="Spline",
             workload="BASELINE configs[4] per-GPU share: 1 level x 1.25e7 synthetic samples per GPU (1e8 over 8 GPUs), Spline "
                      "n_moments=128 (cubic B-spline moments, not part of the reference), mean+var estimate + max-entropy PDF"),
