@@ -11,7 +11,10 @@ namespace mlmc {
 
 constexpr int WAVE = 64;
 constexpr int ACC_THREADS = 256;   // 4 waves, one per SIMD of a CU
-constexpr int MAX_TERMS_PER_PASS = 64;
+#ifndef MLMC_TERMS_PER_PASS
+#define MLMC_TERMS_PER_PASS 64
+#endif
+constexpr int MAX_TERMS_PER_PASS = MLMC_TERMS_PER_PASS;
 
 // ---- error plumbing ---------------------------------------------------------------------
 void set_error(const std::string &msg);

@@ -122,7 +122,8 @@ int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64
 // The accumulation kernel.
 //   RT    : accumulators per lane for sum(d) and sum(d^2): terms [t0, t0 + RT) of this pass (terms >= R, if any,
 //           are computed and discarded, so the loop body is one branch-free basic block)
-//   FIRST : t0 == 0 (every term index is a compile-time constant)
+//   T0C   : first term of the pass when known at compile time (0: first pass, 64: second pass of 64 < R <= 128 -- every
+//           term index and recurrence coefficient is then a constant); -1: t0 is a run-time argument (R > 128)
 // One launch covers up to MAX_SEG segments (= pushed chunks of different levels): every block belongs to one
 // segment and the segments get blocks in proportion to their work, so a whole multi-level estimate is ONE grid
 // with one ramp-up and one tail.  Within a segment each lane walks the samples with a stride, two samples per trip
@@ -161,7 +162,7 @@ struct ReduceTable {
     ReduceTarget t[MAX_SEG];
 };
 
-template <int KIND, int RT, bool PAIR, bool FIRST>
+template <int KIND, int RT, bool PAIR, int T0C>
 __device__ __forceinline__ void accum_samples(const BasisParams &bp, 
                                               const double *__restrict__ fine, const double *__restrict__ coarse,
                                               const uint8_t *__restrict__ mask, int64_t n, int t0, int bid, int nb,
@@ -211,7 +212,13 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp,
         gf1.init(k1 ? tf1 : 0.0, w1, bp);
         if (PAIR) { gc0.init(k0 ? tc0 : 0.0, w0, bp); gc1.init(k1 ? tc1 : 0.0, w1, bp); }
 
-        if (!FIRST) {   // later passes of R > 64: advance the recurrences without accumulating
+        if (T0C > 0) {   // second pass of 64 < R <= 128: advance the recurrences without accumulating, unrolled
+#pragma unroll
+            for (int i = 0; i < T0C; ++i) {
+                gf0.next(i); gf1.next(i);
+                if (PAIR) { gc0.next(i); gc1.next(i); }
+            }
+        } else if (T0C < 0) {   // R > 128: run-time term window (coefficients come through scalar loads)
             for (int i = 0; i < t0; ++i) {
                 gf0.next(i); gf1.next(i);
                 if (PAIR) { gc0.next(i); gc1.next(i); }
@@ -232,11 +239,11 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp,
     }
 }
 
-template <int KIND, int RT, bool FIRST>
+template <int KIND, int RT, int T0C>
 __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, SegTable tab,
                                                               int t0_arg, double *__restrict__ partials,
                                                               int64_t *__restrict__ pcounts) {
-    const int t0 = FIRST ? 0 : t0_arg;
+    const int t0 = T0C >= 0 ? T0C : t0_arg;
     // segment of this block: static indices only, so the table stays in scalar registers
     Seg sg = tab.seg[0];
 #pragma unroll
@@ -252,9 +259,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
     for (int i = 0; i < RT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
     int n_keep = 0, n_rm = 0;
     if (sg.coarse)
-        accum_samples<KIND, RT, true, FIRST>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+        accum_samples<KIND, RT, true, T0C>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
     else
-        accum_samples<KIND, RT, false, FIRST>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+        accum_samples<KIND, RT, false, T0C>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
 
 #ifdef MLMC_PROF
     const unsigned long long prof_r1 = __builtin_amdgcn_s_memrealtime(), prof_c1 = __builtin_amdgcn_s_memtime();
@@ -450,27 +457,30 @@ __global__ __launch_bounds__(ACC_THREADS) void k_spline_accum(BasisParams bp, Se
     }
 }
 
-template <int KIND, int RT>
+template <int KIND, int RT, int T0C>
 static int launch_accum_rt(const BasisParams &bp, const SegTable &tab, int total_blocks, int t0,
                            double *partials, int64_t *pcounts) {
-    hipStream_t st = rt().stream;
-    if (t0 == 0)
-        hipLaunchKernelGGL((k_moments_accum<KIND, RT, true>), dim3(total_blocks), dim3(ACC_THREADS), 0, st, bp, tab, t0, partials, pcounts);
-    else
-        hipLaunchKernelGGL((k_moments_accum<KIND, RT, false>), dim3(total_blocks), dim3(ACC_THREADS), 0, st, bp, tab, t0, partials, pcounts);
+    hipLaunchKernelGGL((k_moments_accum<KIND, RT, T0C>), dim3(total_blocks), dim3(ACC_THREADS), 0, rt().stream, bp, tab, t0, partials,
+                       pcounts);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-template <int KIND, int RT>
+template <int KIND, int RT, int T0C>
 static int occupancy_rt(int *per_cu) {
-    MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, (const void *)k_moments_accum<KIND, RT, true>, ACC_THREADS, 0));
+    MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, (const void *)k_moments_accum<KIND, RT, T0C>, ACC_THREADS, 0));
     return 0;
 }
 
-// register-tile sizes compiled per family; a pass uses the smallest one that holds its terms
-static int pick_rt(int kind, int n_terms) {
+// Register tile of a pass over n_terms terms starting at t0.  First pass: the smallest exact-size tile.  Second pass of
+// a Legendre basis with 64 < R <= 128 (t0 == 64): compile-time window, tiles of 16.  Anything later: the run-time kernel.
+static int pick_rt(int kind, int n_terms, int t0) {
     if (kind == MLMC_IDENTITY) return 4;
+    if (t0 > 0) {
+        if (kind == MLMC_LEGENDRE && t0 == 64) return n_terms <= 16 ? 16 : (n_terms <= 32 ? 32 : (n_terms <= 48 ? 48 : 64));
+        if (kind == MLMC_LEGENDRE && t0 == 32) return n_terms <= 16 ? 16 : 32;
+        return 64;
+    }
     if (kind == MLMC_LEGENDRE) {
         const int opts[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
         for (int o : opts)
@@ -486,8 +496,27 @@ static int pick_rt(int kind, int n_terms) {
 // op 0: *out = resident blocks per CU of the instantiation; op 1: launch
 static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const SegTable *tab, int total_blocks,
                           int t0, double *partials, int64_t *pcounts, int *out) {
-#define MLMC_RT_CASE(KIND, N) \
-    case N: return op == 0 ? occupancy_rt<KIND, N>(out) : launch_accum_rt<KIND, N>(bp, *tab, total_blocks, t0, partials, pcounts)
+#define MLMC_RT_GO(KIND, N, T0C) \
+    (op == 0 ? occupancy_rt<KIND, N, T0C>(out) : launch_accum_rt<KIND, N, T0C>(bp, *tab, total_blocks, t0, partials, pcounts))
+#define MLMC_RT_CASE(KIND, N) case N: return MLMC_RT_GO(KIND, N, 0)
+    if (t0 > 0) {
+        if (bp.kind == MLMC_LEGENDRE && t0 == 64) {
+            switch (rt_sel) {
+                case 16: return MLMC_RT_GO(MLMC_LEGENDRE, 16, 64);
+                case 32: return MLMC_RT_GO(MLMC_LEGENDRE, 32, 64);
+                case 48: return MLMC_RT_GO(MLMC_LEGENDRE, 48, 64);
+                default: return MLMC_RT_GO(MLMC_LEGENDRE, 64, 64);
+            }
+        }
+        if (bp.kind == MLMC_LEGENDRE && t0 == 32)
+            return rt_sel == 16 ? MLMC_RT_GO(MLMC_LEGENDRE, 16, 32) : MLMC_RT_GO(MLMC_LEGENDRE, 32, 32);
+        switch (bp.kind) {
+            case MLMC_LEGENDRE: return MLMC_RT_GO(MLMC_LEGENDRE, 64, -1);
+            case MLMC_MONOMIAL: return MLMC_RT_GO(MLMC_MONOMIAL, 64, -1);
+            case MLMC_FOURIER: return MLMC_RT_GO(MLMC_FOURIER, 64, -1);
+            default: return fail("moments: a later pass needs a polynomial / Fourier basis");
+        }
+    }
     switch (bp.kind) {
         case MLMC_LEGENDRE:
             switch (rt_sel) {
@@ -495,27 +524,23 @@ static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const SegTa
                 MLMC_RT_CASE(MLMC_LEGENDRE, 16); MLMC_RT_CASE(MLMC_LEGENDRE, 20); MLMC_RT_CASE(MLMC_LEGENDRE, 24);
                 MLMC_RT_CASE(MLMC_LEGENDRE, 28); MLMC_RT_CASE(MLMC_LEGENDRE, 32); MLMC_RT_CASE(MLMC_LEGENDRE, 40);
                 MLMC_RT_CASE(MLMC_LEGENDRE, 48); MLMC_RT_CASE(MLMC_LEGENDRE, 56);
-                default: return op == 0 ? occupancy_rt<MLMC_LEGENDRE, 64>(out)
-                                        : launch_accum_rt<MLMC_LEGENDRE, 64>(bp, *tab, total_blocks, t0, partials, pcounts);
+                default: return MLMC_RT_GO(MLMC_LEGENDRE, 64, 0);
             }
         case MLMC_MONOMIAL:
             switch (rt_sel) {
                 MLMC_RT_CASE(MLMC_MONOMIAL, 8); MLMC_RT_CASE(MLMC_MONOMIAL, 16); MLMC_RT_CASE(MLMC_MONOMIAL, 32);
-                default: return op == 0 ? occupancy_rt<MLMC_MONOMIAL, 64>(out)
-                                        : launch_accum_rt<MLMC_MONOMIAL, 64>(bp, *tab, total_blocks, t0, partials, pcounts);
+                default: return MLMC_RT_GO(MLMC_MONOMIAL, 64, 0);
             }
         case MLMC_FOURIER:
             switch (rt_sel) {
                 MLMC_RT_CASE(MLMC_FOURIER, 8); MLMC_RT_CASE(MLMC_FOURIER, 16); MLMC_RT_CASE(MLMC_FOURIER, 32);
-                default: return op == 0 ? occupancy_rt<MLMC_FOURIER, 64>(out)
-                                        : launch_accum_rt<MLMC_FOURIER, 64>(bp, *tab, total_blocks, t0, partials, pcounts);
+                default: return MLMC_RT_GO(MLMC_FOURIER, 64, 0);
             }
-        case MLMC_IDENTITY:
-            return op == 0 ? occupancy_rt<MLMC_IDENTITY, 4>(out)
-                           : launch_accum_rt<MLMC_IDENTITY, 4>(bp, *tab, total_blocks, t0, partials, pcounts);
+        case MLMC_IDENTITY: return MLMC_RT_GO(MLMC_IDENTITY, 4, 0);
         default: return fail("unknown basis kind");
     }
 #undef MLMC_RT_CASE
+#undef MLMC_RT_GO
 }
 
 // Launch the pending segments of `a` (all passes over the terms), then the grid reduction.
@@ -527,14 +552,19 @@ int flush_moments(mlmc_accum *a) {
     const BasisParams &bp = a->basis->p;
     const bool sparse_spline = bp.kind == MLMC_SPLINE;
     if (sparse_spline && R > SPLINE_MAX_R) return fail("spline moments: at most 512 basis functions");
-    for (int t0 = 0; t0 < (sparse_spline ? 1 : R); t0 += MAX_TERMS_PER_PASS) {
-        const int n_terms = (R - t0 < MAX_TERMS_PER_PASS) ? R - t0 : MAX_TERMS_PER_PASS;
-        const int rt_sel = sparse_spline ? R : pick_rt(bp.kind, n_terms);
+    // Terms per pass.  A 64-term tile needs 256 accumulator VGPRs = one wave per SIMD, and a lone wave issues at 6.1
+    // cycles per instruction against 4.4-4.7 for two: Legendre bases with 48 < R <= 64 run as two 32-term passes at two
+    // waves per SIMD (the second pass re-runs the first 32 recurrence steps without accumulating: +29 % instructions,
+    // -15 % time).  R <= 48 is one pass at two waves per SIMD; R > 64 uses 64-term passes.
+    const int pass_terms = (bp.kind == MLMC_LEGENDRE && R > 48 && R <= 64) ? 32 : MAX_TERMS_PER_PASS;
+    for (int t0 = 0; t0 < (sparse_spline ? 1 : R); t0 += pass_terms) {
+        const int n_terms = (R - t0 < pass_terms) ? R - t0 : pass_terms;
+        const int rt_sel = sparse_spline ? R : pick_rt(bp.kind, n_terms, t0);
         const int width = 2 * rt_sel;
         int per_cu = 4;
         if (!sparse_spline) {
-            static int occ_cache[8][65];   // resident blocks per CU of (kind, RT); 0 = not asked yet
-            int &cached = occ_cache[bp.kind & 7][rt_sel];
+            static int occ_cache[8][4][65];   // resident blocks per CU of (kind, pass class, RT); 0 = not asked yet
+            int &cached = occ_cache[bp.kind & 7][t0 == 0 ? 0 : (t0 == 64 ? 1 : (t0 == 32 ? 2 : 3))][rt_sel];
             if (cached == 0)
                 if (int rc = accum_dispatch(0, bp, rt_sel, nullptr, 0, 0, nullptr, nullptr, &cached)) return rc;
             per_cu = cached;
