@@ -472,22 +472,21 @@ static int occupancy_rt(int *per_cu) {
     return 0;
 }
 
-// Register tile of a pass over n_terms terms starting at t0.  First pass: the smallest exact-size tile.  Second pass of
-// a Legendre basis with 64 < R <= 128 (t0 == 64): compile-time window, tiles of 16.  Anything later: the run-time kernel.
+// Register tile of a pass over n_terms terms starting at t0.  First pass: the smallest tile that fits (exact sizes for
+// Legendre).  Later passes with t0 = 32 or 64 (48 < R <= 128): compile-time term window, tiles of 16 / 32 / 48 / 64.
+// Anything later (R > 128): the run-time kernel.
 static int pick_rt(int kind, int n_terms, int t0) {
     if (kind == MLMC_IDENTITY) return 4;
-    if (t0 > 0) {
-        if (kind == MLMC_LEGENDRE && t0 == 64) return n_terms <= 16 ? 16 : (n_terms <= 32 ? 32 : (n_terms <= 48 ? 48 : 64));
-        if (kind == MLMC_LEGENDRE && t0 == 32) return n_terms <= 16 ? 16 : 32;
-        return 64;
-    }
+    if (t0 == 32) return n_terms <= 16 ? 16 : 32;
+    if (t0 == 64) return n_terms <= 16 ? 16 : (n_terms <= 32 ? 32 : (n_terms <= 48 ? 48 : 64));
+    if (t0 > 0) return 64;
     if (kind == MLMC_LEGENDRE) {
         const int opts[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
         for (int o : opts)
             if (n_terms <= o) return o;
         return 64;
     }
-    const int opts[] = {8, 16, 32, 64};
+    const int opts[] = {8, 16, 24, 32, 48, 64};
     for (int o : opts)
         if (n_terms <= o) return o;
     return 64;
@@ -499,21 +498,22 @@ static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const SegTa
 #define MLMC_RT_GO(KIND, N, T0C) \
     (op == 0 ? occupancy_rt<KIND, N, T0C>(out) : launch_accum_rt<KIND, N, T0C>(bp, *tab, total_blocks, t0, partials, pcounts))
 #define MLMC_RT_CASE(KIND, N) case N: return MLMC_RT_GO(KIND, N, 0)
+#define MLMC_RT_LATER(KIND)                                                                                  \
+    if (t0 == 32) return rt_sel == 16 ? MLMC_RT_GO(KIND, 16, 32) : MLMC_RT_GO(KIND, 32, 32);                 \
+    if (t0 == 64) {                                                                                          \
+        switch (rt_sel) {                                                                                    \
+            case 16: return MLMC_RT_GO(KIND, 16, 64);                                                        \
+            case 32: return MLMC_RT_GO(KIND, 32, 64);                                                        \
+            case 48: return MLMC_RT_GO(KIND, 48, 64);                                                        \
+            default: return MLMC_RT_GO(KIND, 64, 64);                                                        \
+        }                                                                                                    \
+    }                                                                                                        \
+    return MLMC_RT_GO(KIND, 64, -1)
     if (t0 > 0) {
-        if (bp.kind == MLMC_LEGENDRE && t0 == 64) {
-            switch (rt_sel) {
-                case 16: return MLMC_RT_GO(MLMC_LEGENDRE, 16, 64);
-                case 32: return MLMC_RT_GO(MLMC_LEGENDRE, 32, 64);
-                case 48: return MLMC_RT_GO(MLMC_LEGENDRE, 48, 64);
-                default: return MLMC_RT_GO(MLMC_LEGENDRE, 64, 64);
-            }
-        }
-        if (bp.kind == MLMC_LEGENDRE && t0 == 32)
-            return rt_sel == 16 ? MLMC_RT_GO(MLMC_LEGENDRE, 16, 32) : MLMC_RT_GO(MLMC_LEGENDRE, 32, 32);
         switch (bp.kind) {
-            case MLMC_LEGENDRE: return MLMC_RT_GO(MLMC_LEGENDRE, 64, -1);
-            case MLMC_MONOMIAL: return MLMC_RT_GO(MLMC_MONOMIAL, 64, -1);
-            case MLMC_FOURIER: return MLMC_RT_GO(MLMC_FOURIER, 64, -1);
+            case MLMC_LEGENDRE: MLMC_RT_LATER(MLMC_LEGENDRE);
+            case MLMC_MONOMIAL: MLMC_RT_LATER(MLMC_MONOMIAL);
+            case MLMC_FOURIER: MLMC_RT_LATER(MLMC_FOURIER);
             default: return fail("moments: a later pass needs a polynomial / Fourier basis");
         }
     }
@@ -528,17 +528,20 @@ static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const SegTa
             }
         case MLMC_MONOMIAL:
             switch (rt_sel) {
-                MLMC_RT_CASE(MLMC_MONOMIAL, 8); MLMC_RT_CASE(MLMC_MONOMIAL, 16); MLMC_RT_CASE(MLMC_MONOMIAL, 32);
+                MLMC_RT_CASE(MLMC_MONOMIAL, 8); MLMC_RT_CASE(MLMC_MONOMIAL, 16); MLMC_RT_CASE(MLMC_MONOMIAL, 24);
+                MLMC_RT_CASE(MLMC_MONOMIAL, 32); MLMC_RT_CASE(MLMC_MONOMIAL, 48);
                 default: return MLMC_RT_GO(MLMC_MONOMIAL, 64, 0);
             }
         case MLMC_FOURIER:
             switch (rt_sel) {
-                MLMC_RT_CASE(MLMC_FOURIER, 8); MLMC_RT_CASE(MLMC_FOURIER, 16); MLMC_RT_CASE(MLMC_FOURIER, 32);
+                MLMC_RT_CASE(MLMC_FOURIER, 8); MLMC_RT_CASE(MLMC_FOURIER, 16); MLMC_RT_CASE(MLMC_FOURIER, 24);
+                MLMC_RT_CASE(MLMC_FOURIER, 32); MLMC_RT_CASE(MLMC_FOURIER, 48);
                 default: return MLMC_RT_GO(MLMC_FOURIER, 64, 0);
             }
         case MLMC_IDENTITY: return MLMC_RT_GO(MLMC_IDENTITY, 4, 0);
         default: return fail("unknown basis kind");
     }
+#undef MLMC_RT_LATER
 #undef MLMC_RT_CASE
 #undef MLMC_RT_GO
 }
@@ -553,10 +556,11 @@ int flush_moments(mlmc_accum *a) {
     const bool sparse_spline = bp.kind == MLMC_SPLINE;
     if (sparse_spline && R > SPLINE_MAX_R) return fail("spline moments: at most 512 basis functions");
     // Terms per pass.  A 64-term tile needs 256 accumulator VGPRs = one wave per SIMD, and a lone wave issues at 6.1
-    // cycles per instruction against 4.4-4.7 for two: Legendre bases with 48 < R <= 64 run as two 32-term passes at two
+    // cycles per instruction against 4.4-4.7 for two: polynomial bases with 48 < R <= 64 run as two 32-term passes at two
     // waves per SIMD (the second pass re-runs the first 32 recurrence steps without accumulating: +29 % instructions,
-    // -15 % time).  R <= 48 is one pass at two waves per SIMD; R > 64 uses 64-term passes.
-    const int pass_terms = (bp.kind == MLMC_LEGENDRE && R > 48 && R <= 64) ? 32 : MAX_TERMS_PER_PASS;
+    // -15 % time; Fourier, whose second pass would repeat the sincos, measured slower that way and keeps one pass).
+    // R <= 48 is one pass at two waves per SIMD; R > 64 uses 64-term passes.
+    const int pass_terms = (bp.kind != MLMC_FOURIER && R > 48 && R <= 64) ? 32 : MAX_TERMS_PER_PASS;
     for (int t0 = 0; t0 < (sparse_spline ? 1 : R); t0 += pass_terms) {
         const int n_terms = (R - t0 < pass_terms) ? R - t0 : pass_terms;
         const int rt_sel = sparse_spline ? R : pick_rt(bp.kind, n_terms, t0);
@@ -570,7 +574,7 @@ int flush_moments(mlmc_accum *a) {
             per_cu = cached;
         }
         if (per_cu < 1) per_cu = 1;
-        if (per_cu > 4) per_cu = 4;
+        if (per_cu > 8) per_cu = 8;
         const int resident = rt().n_cu * per_cu;
         // blocks per segment in proportion to its work: 7 fp64 instructions per pair and term, 4 at level 0 plus the
         // per-sample overhead (measured time ratio pair : level-0 = 1.5 at R = 32)
