@@ -25,6 +25,13 @@ __device__ __forceinline__ double transform_value(const BasisParams &bp, double 
     return t;
 }
 
+// The same for the common configuration (no log, safe_eval clipping), free of run-time switches.
+__device__ __forceinline__ double transform_plain(const BasisParams &bp, double x, bool &keep) {
+    const double t = (x - bp.shift) * bp.scale + bp.ref0;   // two roundings, no contraction
+    keep = (t >= bp.ref0) && (t <= bp.ref1);                // NaN -> false
+    return t;
+}
+
 // Monic Legendre recurrence coefficients g_i = (i-1)^2 / ((2i-1)(2i-3)) as a compile-time table: in the fully
 // unrolled accumulation kernels every index is a constant, so the values become instruction operands
 // (s_mov literals) instead of scalar loads that the wave would have to wait for inside the hot loop.

@@ -162,7 +162,7 @@ struct ReduceTable {
     ReduceTarget t[MAX_SEG];
 };
 
-template <int KIND, int RT, bool PAIR, int T0C>
+template <int KIND, int RT, bool PAIR, int T0C, bool PLAIN>
 __device__ __forceinline__ void accum_samples(const BasisParams &bp, 
                                               const double *__restrict__ fine, const double *__restrict__ coarse,
                                               const uint8_t *__restrict__ mask, int64_t n, int t0, int bid, int nb,
@@ -173,8 +173,10 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp,
     int64_t i0 = gtid, i1 = gtid + T;
     double f0 = 0, f1 = 0, c0 = 0, c1 = 0;
     uint8_t m0 = 1, m1 = 1;
-    if (i0 < n) { f0 = fine[i0]; if (PAIR) c0 = coarse[i0]; if (mask) m0 = mask[i0]; }
-    if (i1 < n) { f1 = fine[i1]; if (PAIR) c1 = coarse[i1]; if (mask) m1 = mask[i1]; }
+    // PLAIN: the common case (linear transform, clipping to the domain, no keep flags from a mask kernel) without the
+    // run-time switches of the general path -- at small R the scalar branches of those switches cost as much as the terms
+    if (i0 < n) { f0 = fine[i0]; if (PAIR) c0 = coarse[i0]; if (!PLAIN && mask) m0 = mask[i0]; }
+    if (i1 < n) { f1 = fine[i1]; if (PAIR) c1 = coarse[i1]; if (!PLAIN && mask) m1 = mask[i1]; }
 
     // Issue-priority time slicing.  The kernel runs two waves per SIMD (VGPR bound) and the SIMD arbiter serves the
     // older wave first: with equal priorities the first-dispatched wave of each SIMD runs at its single-wave rate,
@@ -193,16 +195,19 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp,
         const uint8_t mm0 = m0, mm1 = m1;
         // prefetch the next trip
         const int64_t j0 = i0 + 2 * T, j1 = i1 + 2 * T;
-        if (j0 < n) { f0 = fine[j0]; if (PAIR) c0 = coarse[j0]; if (mask) m0 = mask[j0]; }
-        if (j1 < n) { f1 = fine[j1]; if (PAIR) c1 = coarse[j1]; if (mask) m1 = mask[j1]; }
+        if (j0 < n) { f0 = fine[j0]; if (PAIR) c0 = coarse[j0]; if (!PLAIN && mask) m0 = mask[j0]; }
+        if (j1 < n) { f1 = fine[j1]; if (PAIR) c1 = coarse[j1]; if (!PLAIN && mask) m1 = mask[j1]; }
 
         bool kf0, kf1, kc0 = true, kc1 = true;
-        const double tf0 = transform_value(bp, xf0, kf0);
-        const double tf1 = transform_value(bp, xf1, kf1);
+        const double tf0 = PLAIN ? transform_plain(bp, xf0, kf0) : transform_value(bp, xf0, kf0);
+        const double tf1 = PLAIN ? transform_plain(bp, xf1, kf1) : transform_value(bp, xf1, kf1);
         double tc0 = 0, tc1 = 0;
-        if (PAIR) { tc0 = transform_value(bp, xc0, kc0); tc1 = transform_value(bp, xc1, kc1); }
-        const bool k0 = kf0 && kc0 && (mm0 != 0);
-        const bool k1 = v1 && kf1 && kc1 && (mm1 != 0);
+        if (PAIR) {
+            tc0 = PLAIN ? transform_plain(bp, xc0, kc0) : transform_value(bp, xc0, kc0);
+            tc1 = PLAIN ? transform_plain(bp, xc1, kc1) : transform_value(bp, xc1, kc1);
+        }
+        const bool k0 = kf0 && kc0 && (PLAIN || mm0 != 0);
+        const bool k1 = v1 && kf1 && kc1 && (PLAIN || mm1 != 0);
         n_keep += (int)k0 + (int)k1;
         n_rm += (int)(!k0) + (int)(v1 && !k1);
         const double w0 = k0 ? 1.0 : 0.0, w1 = k1 ? 1.0 : 0.0;
@@ -258,10 +263,14 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
 #pragma unroll
     for (int i = 0; i < RT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
     int n_keep = 0, n_rm = 0;
-    if (sg.coarse)
-        accum_samples<KIND, RT, true, T0C>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
-    else
-        accum_samples<KIND, RT, false, T0C>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+    const bool plain = KIND != MLMC_IDENTITY && !bp.is_log && bp.is_clip && sg.mask == nullptr;   // uniform
+    if (sg.coarse) {
+        if (plain) accum_samples<KIND, RT, true, T0C, true>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+        else accum_samples<KIND, RT, true, T0C, false>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+    } else {
+        if (plain) accum_samples<KIND, RT, false, T0C, true>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+        else accum_samples<KIND, RT, false, T0C, false>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+    }
 
 #ifdef MLMC_PROF
     const unsigned long long prof_r1 = __builtin_amdgcn_s_memrealtime(), prof_c1 = __builtin_amdgcn_s_memtime();
