@@ -14,8 +14,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(src, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)   # gpurun merges into the local copy: newest wins
+    return f[-1] if f else None
 
 
 for cfg in ("c2", "c3", "c6"):
