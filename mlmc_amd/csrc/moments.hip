@@ -244,6 +244,62 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp,
     }
 }
 
+// Small tiles (RT <= 8, the reference's everyday n_moments = 5..10): the work per sample is a few dozen instructions and
+// the kernel sits between the HBM and the issue roof, so what matters is memory-level parallelism -- four samples per
+// lane per trip (eight 8-byte loads in flight, issued a whole trip ahead) instead of two.  Common configuration only.
+template <int KIND, int RT, bool PAIR>
+__device__ __forceinline__ void accum_samples_wide(const BasisParams &bp, const double *__restrict__ fine,
+                                                   const double *__restrict__ coarse, int64_t n, int bid, int nb,
+                                                   double (&s)[RT], double (&sp)[RT], int &n_keep, int &n_rm) {
+    constexpr int S = 4;
+    const int64_t T = (int64_t)nb * ACC_THREADS;
+    int64_t i = (int64_t)bid * ACC_THREADS + threadIdx.x;
+    double f[S], c[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const int64_t ik = i + k * T;
+        f[k] = 0.0;
+        c[k] = 0.0;
+        if (ik < n) { f[k] = fine[ik]; if (PAIR) c[k] = coarse[ik]; }
+    }
+    while (i < n) {
+        double xf[S], xc[S];
+        bool valid[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) { xf[k] = f[k]; xc[k] = c[k]; valid[k] = i + k * T < n; }
+        const int64_t j = i + S * T;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {   // next trip's loads
+            const int64_t jk = j + k * T;
+            if (jk < n) { f[k] = fine[jk]; if (PAIR) c[k] = coarse[jk]; }
+        }
+        TermGen<KIND> gf[S], gc[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            bool kf, kc = true;
+            const double tf = transform_plain(bp, xf[k], kf);
+            const double tc = PAIR ? transform_plain(bp, xc[k], kc) : 0.0;
+            const bool keep = valid[k] && kf && kc;
+            n_keep += (int)keep;
+            n_rm += (int)(valid[k] && !keep);
+            const double w = keep ? 1.0 : 0.0;
+            gf[k].init(keep ? tf : 0.0, w, bp);
+            if (PAIR) gc[k].init(keep ? tc : 0.0, w, bp);
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                double d = gf[k].next(t);
+                if (PAIR) d -= gc[k].next(t);
+                s[t] += d;
+                sp[t] = __builtin_fma(d, d, sp[t]);
+            }
+        }
+        i = j;
+    }
+}
+
 template <int KIND, int RT, int T0C>
 __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, SegTable tab,
                                                               int t0_arg, double *__restrict__ partials,
@@ -264,7 +320,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
     for (int i = 0; i < RT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
     int n_keep = 0, n_rm = 0;
     const bool plain = KIND != MLMC_IDENTITY && !bp.is_log && bp.is_clip && sg.mask == nullptr;   // uniform
-    if (sg.coarse) {
+    constexpr bool WIDE = RT <= 8 && T0C == 0 && KIND != MLMC_IDENTITY;
+    if (WIDE && plain) {
+        if (sg.coarse) accum_samples_wide<KIND, RT, true>(bp, sg.fine, sg.coarse, sg.n, bid, sg.nblocks, s, sp, n_keep, n_rm);
+        else accum_samples_wide<KIND, RT, false>(bp, sg.fine, sg.coarse, sg.n, bid, sg.nblocks, s, sp, n_keep, n_rm);
+    } else if (sg.coarse) {
         if (plain) accum_samples<KIND, RT, true, T0C, true>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
         else accum_samples<KIND, RT, true, T0C, false>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
     } else {
