@@ -143,7 +143,8 @@ struct Seg {
     int block0, nblocks;           // blocks [block0, block0 + nblocks) of the grid work on this segment
 };
 struct SegTable {
-    int nseg, pad;
+    int nseg;
+    int prio_mod;                  // waves per SIMD (= resident blocks per CU) that share the issue priority in turn
     Seg seg[MAX_SEG];
 };
 struct ReduceTarget {
@@ -166,7 +167,7 @@ template <int KIND, int RT, bool PAIR, int T0C, bool PLAIN>
 __device__ __forceinline__ void accum_samples(const BasisParams &bp, 
                                               const double *__restrict__ fine, const double *__restrict__ coarse,
                                               const uint8_t *__restrict__ mask, int64_t n, int t0, int bid, int nb,
-                                              double (&s)[RT], double (&sp)[RT], int &n_keep, int &n_rm) {
+                                              unsigned prio_mod, double (&s)[RT], double (&sp)[RT], int &n_keep, int &n_rm) {
     const int64_t T = (int64_t)nb * ACC_THREADS;
     const int64_t gtid = (int64_t)bid * ACC_THREADS + threadIdx.x;
 
@@ -178,16 +179,17 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp,
     if (i0 < n) { f0 = fine[i0]; if (PAIR) c0 = coarse[i0]; if (!PLAIN && mask) m0 = mask[i0]; }
     if (i1 < n) { f1 = fine[i1]; if (PAIR) c1 = coarse[i1]; if (!PLAIN && mask) m1 = mask[i1]; }
 
-    // Issue-priority time slicing.  The kernel runs two waves per SIMD (VGPR bound) and the SIMD arbiter serves the
-    // older wave first: with equal priorities the first-dispatched wave of each SIMD runs at its single-wave rate,
-    // finishes after ~60 % of the kernel and leaves its neighbour to run alone -- and a lone wave cannot fill the
-    // fp64 pipe (measured 6.1 vs 4.4 cycles per instruction with both).  So the two waves of a SIMD (wave slots of
-    // opposite parity) take turns at the higher priority in slices of 2^PRIO_SLICE_BITS shader cycles read from the
-    // shared clock: both progress at the same average rate and end together (-4 % kernel time at R = 32).
-    const unsigned prio_parity = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1;   // HW_ID.wave_id[0]
+    // Issue-priority time slicing.  The kernel runs two or three waves per SIMD (VGPR bound) and the SIMD arbiter serves
+    // the older wave first: with equal priorities the first-dispatched wave of each SIMD runs at its single-wave rate,
+    // finishes after ~60 % of the kernel and leaves its neighbours to run alone -- and a lone wave cannot fill the
+    // fp64 pipe (measured 6.1 vs 4.4 cycles per instruction with two).  So the prio_mod waves of a SIMD (wave slot
+    // modulo prio_mod = resident blocks per CU) take turns at the higher priority in slices of 2^PRIO_SLICE_BITS
+    // shader cycles read from the shared clock: all progress at the same average rate and end together
+    // (-4 % kernel time at R = 32).
+    const unsigned prio_phase = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u) % prio_mod;   // HW_ID.wave_id
     unsigned long long prio_clock = __builtin_amdgcn_s_memtime();
     while (i0 < n) {
-        if ((((unsigned)(prio_clock >> PRIO_SLICE_BITS)) & 1u) == prio_parity) __builtin_amdgcn_s_setprio(2);
+        if (((unsigned)(prio_clock >> PRIO_SLICE_BITS)) % prio_mod == prio_phase) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(0);
         prio_clock = __builtin_amdgcn_s_memtime();   // read now, used at the next trip: the latency is hidden
         const bool v1 = i1 < n;
@@ -300,7 +302,10 @@ __device__ __forceinline__ void accum_samples_wide(const BasisParams &bp, const 
     }
 }
 
-template <int KIND, int RT, int T0C>
+// PLAIN kernels hold only the switch-free loops (fewer registers: a third wave per SIMD up to RT = 28); the general
+// kernels only the loops with the run-time switches.  The host launches PLAIN when the basis is in the common
+// configuration and no segment carries a mask.
+template <int KIND, int RT, int T0C, bool PLAIN>
 __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, SegTable tab,
                                                               int t0_arg, double *__restrict__ partials,
                                                               int64_t *__restrict__ pcounts) {
@@ -319,19 +324,16 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
 #pragma unroll
     for (int i = 0; i < RT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
     int n_keep = 0, n_rm = 0;
-    const bool plain = KIND != MLMC_IDENTITY && !bp.is_log && bp.is_clip && sg.mask == nullptr;   // uniform
-    constexpr bool WIDE = RT <= 8 && T0C == 0 && KIND != MLMC_IDENTITY;
-    if (WIDE && plain) {
+    const unsigned prio_mod = tab.prio_mod > 0 ? (unsigned)tab.prio_mod : 1u;
+    constexpr bool WIDE = RT <= 8 && T0C == 0;
+    if (PLAIN && WIDE) {
         if (sg.coarse) accum_samples_wide<KIND, RT, true>(bp, sg.fine, sg.coarse, sg.n, bid, sg.nblocks, s, sp, n_keep, n_rm);
         else accum_samples_wide<KIND, RT, false>(bp, sg.fine, sg.coarse, sg.n, bid, sg.nblocks, s, sp, n_keep, n_rm);
     } else if (sg.coarse) {
-        if (plain) accum_samples<KIND, RT, true, T0C, true>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
-        else accum_samples<KIND, RT, true, T0C, false>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+        accum_samples<KIND, RT, true, T0C, PLAIN>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, prio_mod, s, sp, n_keep, n_rm);
     } else {
-        if (plain) accum_samples<KIND, RT, false, T0C, true>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
-        else accum_samples<KIND, RT, false, T0C, false>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, s, sp, n_keep, n_rm);
+        accum_samples<KIND, RT, false, T0C, PLAIN>(bp, sg.fine, sg.coarse, sg.mask, sg.n, t0, bid, sg.nblocks, prio_mod, s, sp, n_keep, n_rm);
     }
-
 #ifdef MLMC_PROF
     const unsigned long long prof_r1 = __builtin_amdgcn_s_memrealtime(), prof_c1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -526,18 +528,18 @@ __global__ __launch_bounds__(ACC_THREADS) void k_spline_accum(BasisParams bp, Se
     }
 }
 
-template <int KIND, int RT, int T0C>
+template <int KIND, int RT, int T0C, bool PLAIN>
 static int launch_accum_rt(const BasisParams &bp, const SegTable &tab, int total_blocks, int t0,
                            double *partials, int64_t *pcounts) {
-    hipLaunchKernelGGL((k_moments_accum<KIND, RT, T0C>), dim3(total_blocks), dim3(ACC_THREADS), 0, rt().stream, bp, tab, t0, partials,
+    hipLaunchKernelGGL((k_moments_accum<KIND, RT, T0C, PLAIN>), dim3(total_blocks), dim3(ACC_THREADS), 0, rt().stream, bp, tab, t0, partials,
                        pcounts);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-template <int KIND, int RT, int T0C>
+template <int KIND, int RT, int T0C, bool PLAIN>
 static int occupancy_rt(int *per_cu) {
-    MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, (const void *)k_moments_accum<KIND, RT, T0C>, ACC_THREADS, 0));
+    MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, (const void *)k_moments_accum<KIND, RT, T0C, PLAIN>, ACC_THREADS, 0));
     return 0;
 }
 
@@ -562,10 +564,11 @@ static int pick_rt(int kind, int n_terms, int t0) {
 }
 
 // op 0: *out = resident blocks per CU of the instantiation; op 1: launch
-static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const SegTable *tab, int total_blocks,
+static int accum_dispatch(int op, bool plain, const BasisParams &bp, int rt_sel, const SegTable *tab, int total_blocks,
                           int t0, double *partials, int64_t *pcounts, int *out) {
-#define MLMC_RT_GO(KIND, N, T0C) \
-    (op == 0 ? occupancy_rt<KIND, N, T0C>(out) : launch_accum_rt<KIND, N, T0C>(bp, *tab, total_blocks, t0, partials, pcounts))
+#define MLMC_RT_GO1(KIND, N, T0C, P) \
+    (op == 0 ? occupancy_rt<KIND, N, T0C, P>(out) : launch_accum_rt<KIND, N, T0C, P>(bp, *tab, total_blocks, t0, partials, pcounts))
+#define MLMC_RT_GO(KIND, N, T0C) (plain ? MLMC_RT_GO1(KIND, N, T0C, true) : MLMC_RT_GO1(KIND, N, T0C, false))
 #define MLMC_RT_CASE(KIND, N) case N: return MLMC_RT_GO(KIND, N, 0)
 #define MLMC_RT_LATER(KIND)                                                                                  \
     if (t0 == 32) return rt_sel == 16 ? MLMC_RT_GO(KIND, 16, 32) : MLMC_RT_GO(KIND, 32, 32);                 \
@@ -607,12 +610,13 @@ static int accum_dispatch(int op, const BasisParams &bp, int rt_sel, const SegTa
                 MLMC_RT_CASE(MLMC_FOURIER, 32); MLMC_RT_CASE(MLMC_FOURIER, 48);
                 default: return MLMC_RT_GO(MLMC_FOURIER, 64, 0);
             }
-        case MLMC_IDENTITY: return MLMC_RT_GO(MLMC_IDENTITY, 4, 0);
+        case MLMC_IDENTITY: return MLMC_RT_GO1(MLMC_IDENTITY, 4, 0, false);
         default: return fail("unknown basis kind");
     }
 #undef MLMC_RT_LATER
 #undef MLMC_RT_CASE
 #undef MLMC_RT_GO
+#undef MLMC_RT_GO1
 }
 
 // Launch the pending segments of `a` (all passes over the terms), then the grid reduction.
@@ -635,11 +639,13 @@ int flush_moments(mlmc_accum *a) {
         const int rt_sel = sparse_spline ? R : pick_rt(bp.kind, n_terms, t0);
         const int width = 2 * rt_sel;
         int per_cu = 4;
+        bool plain = bp.kind != MLMC_IDENTITY && !bp.is_log && bp.is_clip;
+        for (const PendingSeg &p : a->pending) plain = plain && p.mask == nullptr;
         if (!sparse_spline) {
-            static int occ_cache[8][4][65];   // resident blocks per CU of (kind, pass class, RT); 0 = not asked yet
-            int &cached = occ_cache[bp.kind & 7][t0 == 0 ? 0 : (t0 == 64 ? 1 : (t0 == 32 ? 2 : 3))][rt_sel];
+            static int occ_cache[8][4][2][65];   // resident blocks per CU of (kind, pass class, plain, RT); 0 = not asked yet
+            int &cached = occ_cache[bp.kind & 7][t0 == 0 ? 0 : (t0 == 64 ? 1 : (t0 == 32 ? 2 : 3))][plain ? 1 : 0][rt_sel];
             if (cached == 0)
-                if (int rc = accum_dispatch(0, bp, rt_sel, nullptr, 0, 0, nullptr, nullptr, &cached)) return rc;
+                if (int rc = accum_dispatch(0, plain, bp, rt_sel, nullptr, 0, t0, nullptr, nullptr, &cached)) return rc;
             per_cu = cached;
         }
         if (per_cu < 1) per_cu = 1;
@@ -655,6 +661,7 @@ int flush_moments(mlmc_accum *a) {
         std::memset(&tab, 0, sizeof(tab));
         std::memset(&rtab, 0, sizeof(rtab));
         tab.nseg = nseg;
+        tab.prio_mod = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
         int total = 0;
         int64_t bytes = 0;
         for (int k = 0; k < nseg; ++k) {
@@ -696,7 +703,7 @@ int flush_moments(mlmc_accum *a) {
             const size_t lds = sizeof(double) * 4 * 2 * (size_t)(R + 8);
             hipLaunchKernelGGL(k_spline_accum, dim3(total), dim3(ACC_THREADS), lds, st, bp, tab, R, a->d_partials, a->d_pcounts);
             MLMC_HIP_CHECK(hipGetLastError());
-        } else if (int rc = accum_dispatch(1, bp, rt_sel, &tab, total, t0, a->d_partials, a->d_pcounts, nullptr)) {
+        } else if (int rc = accum_dispatch(1, plain, bp, rt_sel, &tab, total, t0, a->d_partials, a->d_pcounts, nullptr)) {
             return rc;
         }
         if (int rc = timing_end(a)) return rc;

@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
     float ms = 0;
     for (int it = 0; it < 300; ++it) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((k_moments_accum<MLMC_LEGENDRE, 32, 0>), dim3(total), dim3(ACC_THREADS), 0, 0, bp, tab, 0, partials, pc);
+        hipLaunchKernelGGL((k_moments_accum<MLMC_LEGENDRE, 32, 0, true>), dim3(total), dim3(ACC_THREADS), 0, 0, bp, tab, 0, partials, pc);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);
