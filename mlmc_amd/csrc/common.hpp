@@ -103,7 +103,7 @@ struct mlmc_accum {
 
 namespace mlmc {
 // moments.hip
-int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, double *d_out);
+int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, double *d_out, double *scratch = nullptr);
 int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64_t n, uint8_t *d_mask, int64_t *d_counts_level);
 int launch_moments_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
                          int64_t n, bool count, bool defer);

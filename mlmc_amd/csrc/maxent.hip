@@ -13,7 +13,11 @@
 //   k_me_solve   : Cholesky of H + tau I in LDS (one workgroup), p = -(H + tau I)^-1 g
 // F is strictly convex, so Newton + Armijo backtracking converges to the same multipliers as the reference's
 // trust-region iterations (which are not pinned by any reference test).
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "device_basis.hpp"
@@ -227,6 +231,335 @@ __global__ void k_me_scale_cols(double *__restrict__ Phi, const double *__restri
     if (idx < (int64_t)Q * R1) Phi[idx] /= sigma[idx % R1];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The damped Newton iteration as ONE cooperative launch (SimpleDistribution's functional, no penalties).
+// The kernel-per-step formulation above pays launch latency and one host round trip per Newton step and per
+// line-search trial (~160 us per step); the problem itself is tiny.  Here NB workgroups each own a slice of QS
+// quadrature points: the slice of the scaled basis sits in LDS for the whole solve, every workgroup computes its
+// partial integral / gradient / Hessian from LDS, the partials are summed in a fixed order after a grid barrier, and
+// EVERY workgroup then runs the same Cholesky solve and takes the same decisions (regularisation, Armijo backtracking
+// -- four step lengths per barrier -- and convergence), so nothing has to be broadcast.  Same algorithm and constants
+// as the host loop of mlmc_maxent_solve, which stays as the path for the penalised functional and as fallback.
+// The grid barrier spins on an agent-scope generation counter with a bounded number of polls: if the workgroups are
+// ever not co-resident the kernel gives up (result[5] = 1) instead of hanging, and the host falls back.
+// ------------------------------------------------------------------------------------------
+constexpr int COOP_THREADS = 256;
+constexpr int COOP_MAX_BLOCKS = 128;
+
+struct CoopArgs {
+    const double *Phi;       // [Q][R1] scaled basis (row-major)
+    const double *w;         // [Q]
+    const double *mu_s;      // [R1]
+    const double *sigma;     // [R1]
+    double *lam;             // [R1] in: start, out: multipliers
+    double *g_out;           // [R1]
+    double *H_out;           // [R1][R1]
+    double *result;          // [8]: nit, success, F, gnorm, moment0, aborted
+    double *part;            // [NB][E] partials, E = npairs + R1 + 1
+    double *tot;             // [E]
+    double *part_ls;         // [NB][4]
+    unsigned *bar;           // [2]: arrival counter (monotonic), generation
+    int Q, R1, NB, QS, max_it;
+    double tol;
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {   // lane must be wave-uniform
+    const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(v), lane);
+    const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(v), lane);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+__device__ __forceinline__ bool coop_barrier(unsigned *bar, unsigned nb, unsigned &gen, int *abort_s) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                     // release this workgroup's global writes (agent scope)
+        ++gen;
+        const unsigned arrived = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (arrived == nb * gen) {
+            __hip_atomic_store(&bar[1], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int polls = 0;
+            while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++polls > (1 << 19)) { *abort_s = 1; break; }   // ~0.1 s: the grid is not co-resident
+            }
+        }
+        __threadfence();                                     // acquire the other workgroups' writes
+    }
+    __syncthreads();
+    return *abort_s == 0;
+}
+
+__global__ __launch_bounds__(COOP_THREADS) void k_me_coop(CoopArgs A) {
+    extern __shared__ double sm[];
+    const int R1 = A.R1, Q = A.Q, QS = A.QS, NB = A.NB;
+    const int R1p = R1 | 1, ld = R1 + 1;
+    const int npairs = R1 * (R1 + 1) / 2, E = npairs + R1 + 1;
+    double *ph = sm;                                   // [QS][R1p]  slice of Phi (whole solve)
+    double *lam = ph + (size_t)QS * R1p;               // [R1]
+    double *trial = lam + R1;                          // [R1]  (not used: step lengths are applied on the fly)
+    double *g = trial + R1;                            // [R1]
+    double *pdir = g + R1;                             // [R1]
+    double *y = pdir + R1;                             // [R1]
+    double *rw = y + R1;                               // [4][QS] rho w of the slice (4 step lengths in the line search)
+    double *wsl = rw + 4 * QS;                         // [QS] weights of the slice
+    double *red = wsl + QS;                            // [16]
+    double *mus = red + 16;                            // [R1] mu_i / sigma_i
+    double *lsum = mus + R1;                           // [4][COOP_MAX_BLOCKS] line-search partials of all workgroups
+    double *Lm = lsum + 4 * COOP_MAX_BLOCKS;           // [R1][ld] Cholesky matrix; aliased by psi [QS][R1p] in phase A
+    double *psi = Lm;
+    __shared__ int abort_s, bad_s;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int q0 = b * QS, nq = max(0, min(QS, Q - q0));
+    unsigned gen = 0;
+    if (tid == 0) abort_s = 0;
+    for (int idx = tid; idx < QS * R1; idx += COOP_THREADS) {
+        const int q = idx / R1, i = idx % R1;
+        ph[q * R1p + i] = q < nq ? A.Phi[(int64_t)(q0 + q) * R1 + i] : 0.0;
+    }
+    for (int q = tid; q < QS; q += COOP_THREADS) wsl[q] = q < nq ? A.w[q0 + q] : 0.0;
+    for (int i = tid; i < R1; i += COOP_THREADS) { lam[i] = A.lam[i]; pdir[i] = 0.0; mus[i] = A.mu_s[i]; }
+    __syncthreads();
+
+    // rho w of the slice for up to 4 step lengths alpha_k = alpha0 / 2^k along pdir; 8 lanes share one (point, k)
+    auto slice_density = [&](double alpha0, int n_alpha) {
+        for (int item = tid >> 3; item < QS * n_alpha; item += COOP_THREADS / 8) {
+            const int k = item / QS, q = item % QS, sub = tid & 7;
+            const double alpha = alpha0 / (double)(1 << k);
+            double power = 0.0;
+            for (int i = sub; i < R1; i += 8) power = __builtin_fma(ph[q * R1p + i], __builtin_fma(alpha, pdir[i], lam[i]), power);
+            power += __shfl_xor(power, 1, 64);
+            power += __shfl_xor(power, 2, 64);
+            power += __shfl_xor(power, 4, 64);
+            if (sub == 0) rw[k * QS + q] = wsl[q] * exp(fmin(fmax(-power, -200.0), 200.0));
+        }
+        __syncthreads();
+    };
+
+    int nit = 0, success = 0, ok = 1;
+    double tau = 0.0, F = 0.0, gnorm = 0.0, moment0 = 0.0, gp = 0.0;
+    // `spec`: the partials of this round are taken at lam + pdir, the full Newton step -- if it passes the Armijo test
+    // (the usual case near the solution) they ARE the next iterate's integral / gradient / Hessian, so an accepted
+    // step costs no line-search round trip at all; otherwise the step lengths 1/2, 1/4, ... are tried four per barrier.
+    bool spec = false;
+    for (int it = 0; it <= A.max_it && ok;) {
+#ifdef MLMC_PROF_COOP
+        unsigned long long st_[8];
+        st_[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+        // ---- phase A: partial integral, gradient and Hessian of this slice at lam (or at lam + pdir) ----
+        slice_density(spec ? 1.0 : 0.0, 1);
+        for (int idx = tid; idx < QS * R1; idx += COOP_THREADS) {
+            const int q = idx / R1, i = idx % R1;
+            psi[q * R1p + i] = ph[q * R1p + i] * rw[q];
+        }
+        __syncthreads();
+        double *mine = A.part + (size_t)b * E;
+        for (int p = tid; p < npairs; p += COOP_THREADS) {
+            // upper triangle, row-major: p = i (2 R1 - i + 1) / 2 + (j - i)
+            int i = (int)floor(((double)(2 * R1 + 1) - sqrt((double)(2 * R1 + 1) * (2 * R1 + 1) - 8.0 * p)) * 0.5);
+            while (i * (2 * R1 - i + 1) / 2 > p) --i;
+            while ((i + 1) * (2 * R1 - i) / 2 <= p) ++i;
+            const int j = i + (p - i * (2 * R1 - i + 1) / 2);
+            double acc = 0.0;
+            for (int q = 0; q < QS; ++q) acc = __builtin_fma(psi[q * R1p + i], ph[q * R1p + j], acc);
+            mine[p] = acc;
+        }
+        for (int i = tid; i < R1; i += COOP_THREADS) {
+            double acc = 0.0;
+            for (int q = 0; q < QS; ++q) acc += psi[q * R1p + i];
+            mine[npairs + i] = acc;
+        }
+        if (tid == 0) {
+            double acc = 0.0;
+            for (int q = 0; q < QS; ++q) acc += rw[q];
+            mine[npairs + R1] = acc;
+        }
+#ifdef MLMC_PROF_COOP
+        st_[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (!coop_barrier(A.bar, NB, gen, &abort_s)) { ok = 0; break; }
+#ifdef MLMC_PROF_COOP
+        st_[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+        // ---- phase B: fixed-order sums of the partials, spread over the grid ----
+        // (8 lanes per entry: the partials of the other workgroups come from remote L2 / HBM, keep the loads parallel)
+        for (int e = b * (COOP_THREADS / 8) + (tid >> 3); e < E; e += NB * (COOP_THREADS / 8)) {
+            double acc = 0.0;
+            for (int k = tid & 7; k < NB; k += 8) acc += A.part[(size_t)k * E + e];
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if ((tid & 7) == 0) A.tot[e] = acc;
+        }
+#ifdef MLMC_PROF_COOP
+        st_[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (!coop_barrier(A.bar, NB, gen, &abort_s)) { ok = 0; break; }
+#ifdef MLMC_PROF_COOP
+        st_[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (spec) {
+            // the totals belong to lam + pdir: Armijo test of the full step (same in every workgroup)
+            spec = false;
+            const double lin0 = F - red[4];                                 // mu~ . lam  (red[4]: integral at lam)
+            const double Ft = (lin0 + red[3]) + A.tot[npairs + R1];
+            bool accepted = Ft == Ft && Ft <= F + 1e-4 * gp;
+            double alpha = 1.0;
+            if (!accepted) {
+                // ---- backtracking: step lengths alpha / 2^k, four per barrier ----
+                alpha = 0.5;
+                for (int batch = 0; batch < 10 && !accepted && ok; ++batch) {
+                    slice_density(alpha, 4);
+                    if (tid < 4) {
+                        double acc = 0.0;
+                        for (int q = 0; q < QS; ++q) acc += rw[tid * QS + q];
+                        A.part_ls[(size_t)(batch & 1) * NB * 4 + (size_t)b * 4 + tid] = acc;
+                    }
+                    if (!coop_barrier(A.bar, NB, gen, &abort_s)) { ok = 0; break; }
+                    for (int idx = tid; idx < NB * 4; idx += COOP_THREADS)      // one parallel sweep over the remote partials
+                        lsum[(idx & 3) * COOP_MAX_BLOCKS + (idx >> 2)] = A.part_ls[(size_t)(batch & 1) * NB * 4 + idx];
+                    __syncthreads();
+                    for (int k = 0; k < 4; ++k) {
+                        const double ak = alpha / (double)(1 << k);
+                        double integral = 0.0;
+                        for (int kb = 0; kb < NB; ++kb) integral += lsum[k * COOP_MAX_BLOCKS + kb];
+                        const double Fk = __builtin_fma(ak, red[3], lin0) + integral;
+                        if (Fk == Fk && Fk <= F + 1e-4 * ak * gp) { accepted = true; alpha = ak; break; }
+                    }
+                    __syncthreads();
+                    if (!accepted) alpha /= 16.0;
+                }
+                if (!ok) break;
+            }
+            if (!accepted) {
+                tau = (tau == 0.0) ? 1e-8 * (1.0 + fabs(F)) : tau * 100.0;
+                if (tau > 1e20) break;
+                continue;                                                   // re-evaluate at lam with the larger shift
+            }
+            __syncthreads();
+            for (int i = tid; i < R1; i += COOP_THREADS) lam[i] = __builtin_fma(alpha, pdir[i], lam[i]);
+            __syncthreads();
+            tau = (alpha == 1.0) ? tau * 0.1 : tau;
+            if (tau < 1e-14) tau = 0.0;
+            ++nit;
+            if (alpha != 1.0) continue;                                     // the totals are not those of the new lam
+        }
+        // ---- phase C (identical in every workgroup): gradient, L D L^T of H + tau I, Newton direction ----
+        for (int i = tid; i < R1; i += COOP_THREADS) g[i] = mus[i] - A.tot[npairs + i];
+        for (int idx = tid; idx < R1 * R1; idx += COOP_THREADS) {
+            int i = idx / R1, j = idx % R1;
+            if (i > j) { const int t = i; i = j; j = t; }
+            Lm[(idx / R1) * ld + (idx % R1)] = A.tot[i * (2 * R1 - i + 1) / 2 + (j - i)] + ((idx / R1) == (idx % R1) ? tau : 0.0);
+        }
+        if (tid == 0) bad_s = 0;
+        __syncthreads();
+#ifdef MLMC_PROF_COOP
+        st_[6] = __builtin_amdgcn_s_memrealtime();
+#endif
+        {
+            double lin = 0.0;
+            for (int k = 0; k < R1; ++k) lin = __builtin_fma(mus[k], lam[k], lin);
+            F = lin + A.tot[npairs + R1];
+            moment0 = A.tot[npairs] * A.sigma[0];
+        }
+        // L D L^T in place, ONE workgroup barrier per column: step k only reads column k (never scales it), so the
+        // trailing update A_ij -= A_ik A_jk / d_k needs no second barrier; afterwards Lm[i][k] = L_ik d_k (i > k) and
+        // Lm[k][k] = d_k.  Positive definite <=> every pivot d_k > 0.
+        for (int k = 0; k < R1; ++k) {
+            const double d = Lm[k * ld + k];
+            if (!(d > 0.0)) {                       // same value in every thread: uniform exit
+                if (tid == 0) bad_s = 1;
+                break;
+            }
+            const double inv_d = 1.0 / d;
+            if (tid == 0) y[k] = inv_d;
+            for (int i = k + 1 + (tid >> 4); i < R1; i += 16) {          // 16 x 16 thread tile over the trailing block
+                const double lik = Lm[i * ld + k] * inv_d;
+                for (int j = k + 1 + (tid & 15); j <= i; j += 16) Lm[i * ld + j] = __builtin_fma(-lik, Lm[j * ld + k], Lm[i * ld + j]);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+#ifdef MLMC_PROF_COOP
+        st_[7] = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (tid < 64) {
+            // triangular solves by one wave, column oriented: lane j carries entries j and j + 64 of the running
+            // right-hand side, every step broadcasts one finished entry (no workgroup barriers, no divisions)
+            const int j0 = tid, j1 = tid + 64;
+            const bool spd = bad_s == 0;
+            double v0 = j0 < R1 ? -g[j0] : 0.0, v1 = j1 < R1 ? -g[j1] : 0.0;
+            const double id0 = j0 < R1 ? y[j0] : 0.0, id1 = j1 < R1 ? y[j1] : 0.0;       // 1 / d_j
+            for (int i = 0; i < R1 && spd; ++i) {                 // L u = -g, then z = D^-1 u (z_i replaces u_i)
+                const double zi = readlane_f64(i < 64 ? v0 : v1, i & 63) * y[i];
+                if (j0 == i) v0 = zi;
+                if (j1 == i) v1 = zi;
+                if (j0 > i && j0 < R1) v0 = __builtin_fma(-Lm[j0 * ld + i], zi, v0);
+                if (j1 > i && j1 < R1) v1 = __builtin_fma(-Lm[j1 * ld + i], zi, v1);
+            }
+            for (int i = R1 - 1; i >= 0 && spd; --i) {            // L^T p = z: p_j = z_j - sum_{i > j} L_ij p_i, L_ij = Lm[i][j] / d_j
+                const double pi = readlane_f64(i < 64 ? v0 : v1, i & 63);
+                if (j0 < i) v0 = __builtin_fma(-Lm[i * ld + j0] * id0, pi, v0);
+                if (j1 < i) v1 = __builtin_fma(-Lm[i * ld + j1] * id1, pi, v1);
+            }
+            if (j0 < R1) pdir[j0] = v0;
+            if (j1 < R1) pdir[j1] = v1;
+            double gn = (j0 < R1 ? g[j0] * g[j0] : 0.0) + (j1 < R1 ? g[j1] * g[j1] : 0.0);
+            double gpv = (j0 < R1 ? g[j0] * v0 : 0.0) + (j1 < R1 ? g[j1] * v1 : 0.0);
+            double lpv = (j0 < R1 ? mus[j0] * v0 : 0.0) + (j1 < R1 ? mus[j1] * v1 : 0.0);
+            gn = wave_sum(gn);
+            gpv = wave_sum(gpv);
+            lpv = wave_sum(lpv);
+            if (tid == 0) {
+                red[0] = sqrt(gn);
+                red[1] = gpv;
+                red[2] = bad_s ? 1.0 : 0.0;
+                red[3] = lpv;                                    // mu~ . p: the linear part of F along the direction
+                red[4] = A.tot[npairs + R1];                     // integral at lam
+            }
+        }
+        __syncthreads();
+#ifdef MLMC_PROF_COOP
+        st_[5] = __builtin_amdgcn_s_memrealtime();
+        if (b == 0 && tid == 0 && it == 3)
+            for (int k = 0; k < 8; ++k) A.result[8 + k] = (double)(st_[k] - st_[0]) / 100.0;   // us
+#endif
+        gnorm = red[0];
+        gp = red[1];
+        const bool not_spd = red[2] != 0.0;
+        if (!(gnorm == gnorm) || !(F == F)) break;
+        if (gnorm < A.tol) { success = 1; break; }
+        if (it == A.max_it) break;
+        ++it;
+        if (not_spd || !(gp < 0.0)) {
+            tau = (tau == 0.0) ? 1e-10 * (1.0 + fabs(F)) : tau * 100.0;
+            if (tau > 1e20) break;
+            continue;
+        }
+        spec = true;                                             // next round: partials at lam + pdir
+    }
+    __syncthreads();
+    if (b == 0) {
+        for (int i = tid; i < R1; i += COOP_THREADS) { A.lam[i] = lam[i]; A.g_out[i] = g[i]; }
+        if (ok)
+            for (int idx = tid; idx < R1 * R1; idx += COOP_THREADS) {
+                int i = idx / R1, j = idx % R1;
+                if (i > j) { const int t = i; i = j; j = t; }
+                A.H_out[idx] = A.tot[i * (2 * R1 - i + 1) / 2 + (j - i)];
+            }
+        if (tid == 0) {
+            A.result[0] = (double)nit;
+            A.result[1] = (double)success;
+            A.result[2] = F;
+            A.result[3] = gnorm;
+            A.result[4] = moment0;
+            A.result[5] = ok ? 0.0 : 1.0;
+        }
+    }
+}
+
 // density(x) = exp(clip(-sum_r c_r Q_r(x), +-200)), c = effective coefficients in the underlying (scaled) family
 template <int KIND>
 __global__ void k_density(BasisParams bp, const double *__restrict__ c, int R,
@@ -313,8 +646,26 @@ static std::vector<double> effective_coeffs(const mlmc_basis *b, const double *l
 struct DevPool {
     char *base = nullptr;
     size_t used = 0, cap = 0;
-    ~DevPool() { if (base) (void)hipFree(base); }
+    bool owner = true;
+    ~DevPool() { if (base && owner) (void)hipFree(base); }
     int reserve(size_t bytes) { MLMC_HIP_CHECK(hipMalloc((void **)&base, bytes)); cap = bytes; return 0; }
+    // view of the process-wide workspace of the max-entropy solver (grow-only; solves are serialised on the stream)
+    int reserve_shared(size_t bytes) {
+        static char *g_base = nullptr;
+        static size_t g_cap = 0;
+        if (bytes > g_cap) {
+            MLMC_HIP_CHECK(hipStreamSynchronize(rt().stream));
+            if (g_base) (void)hipFree(g_base);
+            g_base = nullptr;
+            g_cap = 0;
+            MLMC_HIP_CHECK(hipMalloc((void **)&g_base, bytes));
+            g_cap = bytes;
+        }
+        base = g_base;
+        cap = g_cap;
+        owner = false;
+        return 0;
+    }
     static size_t pad(size_t n_doubles) { return ((n_doubles * sizeof(double) + 255) / 256) * 256 + 256; }
     double *take(size_t n_doubles) {
         double *p = (double *)(base + used);
@@ -367,27 +718,62 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
     const int T = (R1 + 15) / 16;
     const int n_dblocks = (Q + 255) / 256;
     DevPool pool;
+    // cooperative solver geometry: QS quadrature points per workgroup, NB workgroups
+    const bool use_pen_opts = (opts->penalty_coef != 0.0) || (opts->stab_penalty != 0.0);
+    int QS = R1 <= 64 ? 32 : 16;
+    while ((Q + QS - 1) / QS > COOP_MAX_BLOCKS) QS += 8;
+    const int NB = (Q + QS - 1) / QS;
+    const int R1p = R1 | 1;
+    const size_t coop_E = (size_t)R1 * (R1 + 1) / 2 + R1 + 1;
+    const size_t coop_alias = std::max((size_t)R1 * (R1 + 1), (size_t)QS * R1p);
+    const size_t coop_lds = sizeof(double) * ((size_t)QS * R1p + 6 * (size_t)R1 + 5 * (size_t)QS + 16 + 4 * COOP_MAX_BLOCKS + coop_alias);
+    static const bool stepwise_forced = getenv("MLMC_MAXENT_STEPWISE") != nullptr;      // validation aid
+    const bool coop = !stepwise_forced && !use_pen_opts && n_prev == 0 && coop_lds <= 156 * 1024 && NB <= rt().n_cu;
     const size_t sizes[] = {(size_t)R1, (size_t)Q, (size_t)Q, (size_t)Q * R1, (size_t)Q, (size_t)R1, (size_t)R1, (size_t)R1, (size_t)R1,
-                            (size_t)R1 * R1, (size_t)R1, (size_t)R1, 8, (size_t)n_dblocks, (size_t)2 * R1, (size_t)R1 + 1, 4, (size_t)4 * R1};
+                            (size_t)R1 * R1, (size_t)R1, (size_t)R1, 8, (size_t)n_dblocks, (size_t)2 * R1, (size_t)R1 + 1, 4, (size_t)4 * R1,
+                            coop ? (size_t)NB * coop_E : 1, coop ? coop_E : 1, (size_t)2 * COOP_MAX_BLOCKS * 4, 16, 8,
+                            b->out_size > 0 ? (size_t)Q * b->p.size : 1, (size_t)2 * Q + 3 * (size_t)R1,
+                            16 + 2 * (size_t)R1 + (size_t)R1 * R1};
     size_t total = 0;
     for (size_t sz : sizes) total += DevPool::pad(sz);
-    if (pool.reserve(total)) return 1;
-    DevBuf d_dir, d_x, d_w, d_Phi, d_rhow, d_lam, d_trial, d_p, d_g, d_H, d_mus, d_sig, d_scal, d_bs, d_end, d_prev, d_endpts, d_endphi;
+    if (pool.reserve_shared(total)) return 1;
+    DevBuf d_dir, d_x, d_w, d_Phi, d_rhow, d_lam, d_trial, d_p, d_g, d_H, d_mus, d_sig, d_scal, d_bs, d_end, d_prev, d_endpts, d_endphi,
+        d_part, d_tot, d_pls, d_res, d_bar, d_evtmp, d_in, d_outblk;
     DevBuf *bufs[] = {&d_dir, &d_x, &d_w, &d_Phi, &d_rhow, &d_lam, &d_trial, &d_p, &d_g, &d_H, &d_mus, &d_sig, &d_scal, &d_bs, &d_end,
-                      &d_prev, &d_endpts, &d_endphi};
-    for (int k = 0; k < 18; ++k) {
+                      &d_prev, &d_endpts, &d_endphi, &d_part, &d_tot, &d_pls, &d_res, &d_bar, &d_evtmp, &d_in, &d_outblk};
+    for (int k = 0; k < 26; ++k) {
         bufs[k]->p = pool.take(sizes[k]);
         if (!bufs[k]->p) return fail("mlmc_maxent_solve: internal pool overflow");
     }
-    std::vector<double> mus(R1);
-    for (int i = 0; i < R1; ++i) mus[i] = mu[i] / sigma[i];
-    MLMC_HIP_CHECK(hipMemcpyAsync(d_x.p, xq.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
-    MLMC_HIP_CHECK(hipMemcpyAsync(d_w.p, wq.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
-    MLMC_HIP_CHECK(hipMemcpyAsync(d_mus.p, mus.data(), sizeof(double) * R1, hipMemcpyHostToDevice, st));
-    MLMC_HIP_CHECK(hipMemcpyAsync(d_sig.p, sigma, sizeof(double) * R1, hipMemcpyHostToDevice, st));
-    MLMC_HIP_CHECK(hipMemcpyAsync(d_lam.p, lambda_io, sizeof(double) * R1, hipMemcpyHostToDevice, st));
+    // inputs travel as ONE block through a pinned staging buffer: x | w | mu / sigma | sigma | lambda;
+    // results come back the same way: result[16] | lambda | gradient | Hessian
+    const size_t n_in = 2 * (size_t)Q + 3 * (size_t)R1, n_out = 16 + 2 * (size_t)R1 + (size_t)R1 * R1;
+    static double *h_stage = nullptr;
+    static size_t h_stage_cap = 0;
+    if (n_in + n_out > h_stage_cap) {
+        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        if (h_stage) (void)hipHostFree(h_stage);
+        h_stage = nullptr;
+        h_stage_cap = 0;
+        MLMC_HIP_CHECK(hipHostMalloc((void **)&h_stage, sizeof(double) * (n_in + n_out), hipHostMallocDefault));
+        h_stage_cap = n_in + n_out;
+    }
+    d_x.p = d_in.p;
+    d_w.p = d_in.p + Q;
+    d_mus.p = d_in.p + 2 * (size_t)Q;
+    d_sig.p = d_mus.p + R1;
+    d_lam.p = d_sig.p + R1;
+    d_res.p = d_outblk.p;
+    d_g.p = d_outblk.p + 16 + R1;
+    d_H.p = d_g.p + R1;
+    std::memcpy(h_stage, xq.data(), sizeof(double) * Q);
+    std::memcpy(h_stage + Q, wq.data(), sizeof(double) * Q);
+    for (int i = 0; i < R1; ++i) h_stage[2 * (size_t)Q + i] = mu[i] / sigma[i];
+    std::memcpy(h_stage + 2 * (size_t)Q + R1, sigma, sizeof(double) * R1);
+    std::memcpy(h_stage + 2 * (size_t)Q + 2 * (size_t)R1, lambda_io, sizeof(double) * R1);
+    MLMC_HIP_CHECK(hipMemcpyAsync(d_in.p, h_stage, sizeof(double) * n_in, hipMemcpyHostToDevice, st));
     if (n_prev > 0) MLMC_HIP_CHECK(hipMemcpyAsync(d_prev.p, prev_lambda, sizeof(double) * n_prev, hipMemcpyHostToDevice, st));
-    if (int rc = launch_eval(b, d_x.d(), Q, R1, d_Phi.d())) return rc;
+    if (int rc = launch_eval(b, d_x.d(), Q, R1, d_Phi.d(), b->out_size > 0 ? d_evtmp.d() : nullptr)) return rc;
     hipLaunchKernelGGL(k_me_scale_cols, dim3(((size_t)Q * R1 + 255) / 256), dim3(256), 0, st, d_Phi.d(), d_sig.d(), Q, R1);
     MLMC_HIP_CHECK(hipGetLastError());
 
@@ -406,6 +792,43 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
             if (opts->decay_right) ed[R1 + i] = (-phi[2 * R1 + i] + phi[3 * R1 + i]) / eps / sigma[i];
         }
         MLMC_HIP_CHECK(hipMemcpyAsync(d_end.p, ed.data(), sizeof(double) * 2 * R1, hipMemcpyHostToDevice, st));
+    }
+
+    // ---- the whole iteration as one cooperative launch (k_me_coop); falls back to the step-by-step loop below ----
+    if (coop) {
+        MLMC_HIP_CHECK(hipFuncSetAttribute((const void *)k_me_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds));
+        MLMC_HIP_CHECK(hipMemsetAsync(d_bar.p, 0, 64, st));
+        CoopArgs ca;
+        ca.Phi = d_Phi.d(); ca.w = d_w.d(); ca.mu_s = d_mus.d(); ca.sigma = d_sig.d();
+        ca.lam = d_lam.d(); ca.g_out = d_g.d(); ca.H_out = d_H.d(); ca.result = d_res.d();
+        ca.part = d_part.d(); ca.tot = d_tot.d(); ca.part_ls = d_pls.d(); ca.bar = (unsigned *)d_bar.p;
+        ca.Q = Q; ca.R1 = R1; ca.NB = NB; ca.QS = QS; ca.max_it = max_it; ca.tol = tol;
+        hipLaunchKernelGGL(k_me_coop, dim3(NB), dim3(COOP_THREADS), coop_lds, st, ca);
+        MLMC_HIP_CHECK(hipGetLastError());
+        // the final multipliers are written next to the result block: one copy brings everything back
+        hipLaunchKernelGGL(k_me_axpy, dim3((R1 + 127) / 128), dim3(128), 0, st, d_lam.d(), d_lam.d(), 0.0, R1, d_outblk.p + 16);
+        double *res = h_stage + n_in;
+        MLMC_HIP_CHECK(hipMemcpyAsync(res, d_outblk.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, st));
+        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+#ifdef MLMC_PROF_COOP
+        fprintf(stderr, "coop stamps (us): A %.1f | bar1 %.1f | B %.1f | bar2 %.1f | C %.1f = load %.1f + ldl %.1f + solve %.1f (NB %d QS %d R1 %d)\n", res[9], res[10] - res[9],
+                res[11] - res[10], res[12] - res[11], res[13] - res[12], res[14] - res[12], res[15] - res[14], res[13] - res[15], NB, QS, R1);
+#endif
+        if (res[5] == 0.0) {
+            std::memcpy(lambda_io, res + 16, sizeof(double) * R1);
+            if (grad_out) std::memcpy(grad_out, res + 16 + R1, sizeof(double) * R1);
+            if (hess_out) std::memcpy(hess_out, res + 16 + 2 * (size_t)R1, sizeof(double) * (size_t)R1 * R1);
+            info->nit = (int)res[0];
+            info->success = (int)res[1];
+            info->fun = res[2];
+            info->grad_norm = res[3];
+            info->moment0 = res[4];
+            info->n_quad = Q;
+            info->reserved = 0;
+            return 0;
+        }
+        // the grid was not co-resident (another tenant held the CUs): start again from the caller's multipliers, step by step
+        MLMC_HIP_CHECK(hipMemcpyAsync(d_lam.p, lambda_io, sizeof(double) * R1, hipMemcpyHostToDevice, st));
     }
 
     double scal[8];

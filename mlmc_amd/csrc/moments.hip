@@ -49,7 +49,7 @@ __global__ void k_apply_matrix(const double *__restrict__ phi, const double *__r
     out[idx] = acc;
 }
 
-int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, double *d_out) {
+int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, double *d_out, double *scratch) {
     if (n == 0) return 0;
     hipStream_t st = rt().stream;
     int threads = 256;
@@ -60,7 +60,8 @@ int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, dou
     int esize = size;
     if (b->out_size > 0) {   // evaluate all R0 underlying terms, then apply the matrix
         esize = bp.size;
-        MLMC_HIP_CHECK(hipMalloc(&d_tmp, sizeof(double) * (size_t)n * esize));
+        if (scratch) d_tmp = scratch;   // caller's workspace of n * (underlying size) doubles: no allocation, no sync
+        else MLMC_HIP_CHECK(hipMalloc(&d_tmp, sizeof(double) * (size_t)n * esize));
         target = d_tmp;
     }
     switch (bp.kind) {
@@ -76,8 +77,10 @@ int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, dou
         int64_t tot = n * size;
         hipLaunchKernelGGL(k_apply_matrix, dim3((tot + 255) / 256), dim3(256), 0, st, d_tmp, b->d_matrix, n, bp.size, size, d_out);
         MLMC_HIP_CHECK(hipGetLastError());
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
-        MLMC_HIP_CHECK(hipFree(d_tmp));
+        if (!scratch) {
+            MLMC_HIP_CHECK(hipStreamSynchronize(st));
+            MLMC_HIP_CHECK(hipFree(d_tmp));
+        }
     }
     return 0;
 }
