@@ -727,7 +727,7 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
     const size_t coop_E = (size_t)R1 * (R1 + 1) / 2 + R1 + 1;
     const size_t coop_alias = std::max((size_t)R1 * (R1 + 1), (size_t)QS * R1p);
     const size_t coop_lds = sizeof(double) * ((size_t)QS * R1p + 6 * (size_t)R1 + 5 * (size_t)QS + 16 + 4 * COOP_MAX_BLOCKS + coop_alias);
-    static const bool stepwise_forced = getenv("MLMC_MAXENT_STEPWISE") != nullptr;      // validation aid
+    const bool stepwise_forced = getenv("MLMC_MAXENT_STEPWISE") != nullptr;             // validation aid (tests compare both paths)
     const bool coop = !stepwise_forced && !use_pen_opts && n_prev == 0 && coop_lds <= 156 * 1024 && NB <= rt().n_cu;
     const size_t sizes[] = {(size_t)R1, (size_t)Q, (size_t)Q, (size_t)Q * R1, (size_t)Q, (size_t)R1, (size_t)R1, (size_t)R1, (size_t)R1,
                             (size_t)R1 * R1, (size_t)R1, (size_t)R1, 8, (size_t)n_dblocks, (size_t)2 * R1, (size_t)R1 + 1, 4, (size_t)4 * R1,

@@ -710,3 +710,48 @@ def test_synth_generation_matches_the_reference_chain(hip):
     # a 1-ulp difference of the normal (|y| < 8) is at most 8.9e-16 in absolute terms, also after x + h sqrt(1e-4 + |x|)
     assert np.max(np.abs(got - want)) < 2e-15, np.max(np.abs(got - want))
     assert exact > 0.99, exact
+
+
+def test_maxent_cooperative_launch_matches_the_step_by_step_solver(hip):
+    """k_me_coop (whole Newton iteration in one cooperative launch) against the kernel-per-step loop it replaces
+    (MLMC_MAXENT_STEPWISE=1), on moments of known densities: same convergence flag, multipliers, gradient, Hessian;
+    including a far-off start (regularisation + backtracking), an unreachable tolerance (iteration cap), R1 = 1, 2,
+    64 / 65 (both layouts of the slices) and 128, a finer quadrature, and the moments of the solution reproduced."""
+    from scipy import stats
+    from mlmc_amd import Legendre
+    from mlmc_amd.tool import simple_distribution as sd
+    dom = (-4.0, 6.0)
+    pdf = lambda x: 0.6 * stats.norm(0.5, 1.0).pdf(x) + 0.4 * stats.norm(2.5, 0.7).pdf(x)
+    cases = [(1, None, 1e-8, 100, 0), (2, None, 1e-8, 100, 0), (9, None, 1e-10, 100, 0), (26, None, 1e-8, 100, 0),
+             (26, "far", 1e-8, 100, 0), (26, None, 1e-300, 7, 0), (64, None, 1e-8, 100, 0), (65, None, 1e-8, 100, 0),
+             (128, None, 1e-7, 100, 0), (21, None, 1e-9, 100, 200)]
+    for R, start, tol, max_it, n_int in cases:
+        fn = Legendre(R, dom)
+        mom = sd.compute_semiexact_moments(fn, pdf)
+        err = np.ones(R)
+        lam0 = np.zeros(R)
+        lam0[0] = -np.log(1.0 / (dom[1] - dom[0]))
+        if start == "far":
+            lam0 = lam0 + 3.0 * np.sin(np.arange(R))
+        out = {}
+        for mode in ("coop", "step"):
+            if mode == "step":
+                os.environ["MLMC_MAXENT_STEPWISE"] = "1"
+            try:
+                out[mode] = sd._solve_on_device(fn, mom, err, dom, lam0, tol, max_it, n_intervals=n_int)
+            finally:
+                os.environ.pop("MLMC_MAXENT_STEPWISE", None)
+        (l1, g1, h1, i1), (l2, g2, h2, i2) = out["coop"], out["step"]
+        tag = (R, start, tol)
+        assert i1.success == i2.success and abs(i1.nit - i2.nit) <= 1, (tag, i1.nit, i2.nit, i1.success, i2.success)
+        if tol > 1e-100:
+            assert i1.success == 1 and i1.grad_norm < tol, (tag, i1.grad_norm)
+            scale = max(1.0, np.max(np.abs(l2)))
+            assert np.max(np.abs(l1 - l2)) < 1e-6 * scale, (tag, np.max(np.abs(l1 - l2)))
+            assert np.allclose(h1, h2, rtol=1e-6, atol=1e-9 * np.max(np.abs(h2))), tag
+            assert np.allclose(h1, h1.T) and np.all(np.linalg.eigvalsh(h1) > 0), tag
+            # the moments of the reconstructed density are the prescribed ones
+            got = sd.compute_semiexact_moments(fn, lambda x: sd._device_density(fn, l1, err, x))
+            assert np.max(np.abs(got - mom)) < 50 * tol + 1e-7, (tag, np.max(np.abs(got - mom)))
+        else:
+            assert i1.success == 0 and i1.nit <= max_it
