@@ -87,6 +87,11 @@ int mlmc_basis_eval(const mlmc_basis *b, const double *x, int64_t n, int32_t siz
 /* One accumulator = one estimate_mean() call (quantity_estimate.py:22-80) over `n_levels` levels of a
  * quantity with `n_comp` (= M) scalar components; rows K = n_comp * R (MOMENTS) or n_comp * R * R (COV),
  * row index m * R + r / m * R * R + i * R + j (mom_at_bottom / cov_at_bottom = True layout). */
+/* mode may carry MLMC_MODE_MEAN_ONLY: the caller will read only the sums s (level means), so the passes that exist
+ * solely for sp are skipped -- the covariance accumulates one Gram matrix (D^T S) instead of three, TransformedMoments
+ * skip their diff-Gram pass; the skipped sp come back as NaN.  (Estimate.construct_density, estimator.py:304-331, uses
+ * only the means of both of its estimates.) */
+#define MLMC_MODE_MEAN_ONLY 0x100
 int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32_t n_comp, mlmc_accum **out);
 void mlmc_accum_destroy(mlmc_accum *a);
 int mlmc_accum_reset(mlmc_accum *a);

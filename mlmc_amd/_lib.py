@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MLMC_HIP_LIB", os.path.join(_HERE, "libmlmc_hip.so"))
 
 LEGENDRE, MONOMIAL, FOURIER, IDENTITY, SPLINE = 0, 1, 2, 3, 4
 MODE_MOMENTS, MODE_COV = 0, 1
+MODE_MEAN_ONLY = 0x100
 HOST, DEVICE = 0, 1
 FLAG_TIMING = 1
 

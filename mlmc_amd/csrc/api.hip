@@ -224,6 +224,8 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     if (need_runtime()) return 1;
     if (!b || !out) return fail("mlmc_accum_create: null argument");
     if (n_levels <= 0 || n_comp <= 0) return fail("mlmc_accum_create: n_levels and n_comp must be > 0");
+    const bool mean_only = (mode & MLMC_MODE_MEAN_ONLY) != 0;
+    mode &= ~MLMC_MODE_MEAN_ONLY;
     if (mode != MLMC_MODE_MOMENTS && mode != MLMC_MODE_COV) return fail("mlmc_accum_create: unknown mode");
     if (mode == MLMC_MODE_COV && b->out_size > 64)
         return fail("mlmc_accum_create: covariance of TransformedMoments supports at most 64 moments on the device path");
@@ -232,6 +234,9 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->basis = b;
     a->n_levels = n_levels;
     a->mode = mode;
+    // only the passes that exist solely for the second moments are skipped: the three-Gram covariance pass becomes one
+    // Gram matrix, the diff-Gram pass of TransformedMoments disappears; plain moments keep their (free) sum of squares
+    a->mean_only = mean_only && ((mode == MLMC_MODE_COV && b->out_size == 0) || (mode == MLMC_MODE_MOMENTS && b->out_size > 0));
     a->n_comp = n_comp;
     a->R = b->p.size;
     a->Rout = b->out_size > 0 ? b->out_size : b->p.size;
@@ -346,7 +351,7 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             // chunks that stay valid until finalize (device memory, no staging / mask scratch) are gathered into one launch
             const bool defer = mem_kind == MLMC_DEVICE && a->n_comp == 1;
             rc = launch_moments_accum(a, level, m, f_m, c_m, d_mask, n, count, defer);
-            if (!rc && a->basis->out_size > 0) rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, false, true);
+            if (!rc && a->basis->out_size > 0 && !a->mean_only) rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, false, 1);
         } else if (a->basis->out_size > 0) {
             // covariance of TransformedMoments: materialise the transformed moment values chunk by chunk
             // (eval + matrix product), then the MFMA covariance kernel reads them back
@@ -372,7 +377,7 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
                                                      d_mask ? d_mask + off : nullptr, m_n, count);
             }
         } else {
-            rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, count, false);
+            rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, count, a->mean_only ? 2 : 0);
         }
         if (rc) return rc;
     }

@@ -67,6 +67,7 @@ struct PendingSeg {   // a pushed chunk waiting for the next accumulation launch
 struct mlmc_accum {
     const mlmc_basis *basis = nullptr;
     int n_levels = 0, mode = 0, n_comp = 1;
+    bool mean_only = false;       // MLMC_MODE_MEAN_ONLY: the second moments (sp) are not accumulated
     int R = 0;            // underlying family size
     int Rout = 0;         // rows per component seen by the caller (transform applied)
     int64_t K = 0;        // caller rows per level = n_comp * Rout (* Rout)
@@ -111,7 +112,7 @@ int flush_moments(mlmc_accum *a);
 int launch_moments_finalize(mlmc_accum *a);
 // cov.hip
 int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
-                     int64_t n, bool count, bool diff_gram_only);
+                     int64_t n, bool count, int gram_mode);
 int launch_cov_finalize(mlmc_accum *a);
 int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_vf, const double *d_vc, const uint8_t *d_mask,
                            int64_t n, bool count);

@@ -23,7 +23,8 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int COV_BATCH = 64;
 constexpr int COV_LDS_STRIDE = 66;   // doubles per term row: == 2 (mod 32) -> ds_read_b64 fragments hit 32 distinct bank pairs
 
-// MODE 0: G0, G1, G2 (covariance mean + variance);  MODE 1: G = D^T D only (variance of transformed moments)
+// MODE 0: G0, G1, G2 (covariance mean + variance);  MODE 1: G = D^T D only (variance of transformed moments);
+// MODE 2: G0 = D^T S only (covariance mean without its variance, e.g. Estimate.construct_density)
 // BI, BJ (T = 4 only): the 64 x 64 output block (rows = terms [64 BI, 64 BI + 64), columns = terms [64 BJ, ...)) of
 // a covariance with more than 64 moments; off-diagonal blocks keep two term windows in LDS (one workgroup per CU).
 // VALS: `fine` / `coarse` hold already evaluated moment values [n][R] (row-major, NaN rows = masked samples) instead
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
                         acc[1][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, fb * fb, acc[1][J], 0, 0, 0);
                     }
                 } else {
-                    acc[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, acc[0][J], 0, 0, 0);
+                    acc[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, MODE == 2 ? sb : db, acc[0][J], 0, 0, 0);
                 }
             }
         }
@@ -414,7 +415,7 @@ template <int KIND, int T, int MODE, int BI, int BJ>
 static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, const double *d_f, const double *d_c,
                         const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
     hipStream_t st = rt().stream;
-    if constexpr (T == 4 && BI == BJ) {   // diagonal 64 x 64 block: symmetric, wave-specialised kernel
+    if constexpr (T == 4 && BI == BJ && MODE != 2) {   // diagonal 64 x 64 block: symmetric, wave-specialised kernel
         if (pair)
             hipLaunchKernelGGL((k_cov_accum_t4<KIND, true, MODE, BI>), dim3(blocks), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
         else
@@ -488,14 +489,15 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
 }
 
 int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
-                     int64_t n, bool count, bool diff_gram_only) {
+                     int64_t n, bool count, int gram_mode) {
+    const bool diff_gram_only = gram_mode == 1;   // gram_mode: 0 = G0, G1, G2; 1 = D^T D into the moments' Gram slot; 2 = G0 only
     if (n == 0) return 0;
     const int R = a->R;
     if (R > 128) return fail("covariance accumulation supports at most 128 moments on the device path");
     hipStream_t st = rt().stream;
     const int T = (R <= 16) ? 1 : (R <= 32 ? 2 : 4);
     const int NT = 16 * T, NSL = 4 / T;
-    const int NG = diff_gram_only ? 1 : 3;
+    const int NG = gram_mode == 0 ? 3 : 1;
     const int NB = (R + 63) / 64;          // 64 x 64 output blocks per dimension
     const bool pair = d_c != nullptr;
     const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
@@ -514,7 +516,8 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
             if (timed) if (int rc = timing_begin(a)) return rc;
             int rc;
 #define MLMC_COV_DISPATCH(KIND)                                                                                               \
-    rc = diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, bi, bj, pair, blocks, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
+    rc = gram_mode == 2 ? launch_cov_kind<KIND, 2>(bp, T, bi, bj, pair, blocks, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
+       : diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, bi, bj, pair, blocks, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
                         : launch_cov_kind<KIND, 0>(bp, T, bi, bj, pair, blocks, d_f, d_c, d_mask, n, R, a->d_partials, pc)
             switch (bp.kind) {
                 case MLMC_LEGENDRE: MLMC_COV_DISPATCH(MLMC_LEGENDRE); break;
@@ -545,7 +548,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
 __global__ void k_cov_finalize(const double *__restrict__ totals, const double *__restrict__ scale_c, int R, int RP,
                                int64_t int_width, double *__restrict__ out_s, double *__restrict__ out_sp,
                                const int64_t *__restrict__ counts, int n_levels, int64_t *__restrict__ out_n,
-                               double *__restrict__ out_nd) {
+                               double *__restrict__ out_nd, int mean_only) {
     const int lc = blockIdx.y;
     if (lc == 0 && blockIdx.x == 0)
         for (int l = threadIdx.x; l < n_levels; l += blockDim.x) {
@@ -563,7 +566,8 @@ __global__ void k_cov_finalize(const double *__restrict__ totals, const double *
     const double ci = scale_c ? scale_c[i] : 1.0, cj = scale_c ? scale_c[j] : 1.0;   // nullptr: sums of true values
     const double cc = ci * cj;
     out_s[(int64_t)lc * R * R + idx] = 0.5 * cc * (G0[i * RP + j] + G0[j * RP + i]);
-    out_sp[(int64_t)lc * R * R + idx] = 0.25 * (cc * cc) * ((G1[i * RP + j] + G1[j * RP + i]) + 2.0 * G2[i * RP + j]);
+    out_sp[(int64_t)lc * R * R + idx] = mean_only ? __builtin_nan("")   // MLMC_MODE_MEAN_ONLY: not accumulated
+                                                  : 0.25 * (cc * cc) * ((G1[i * RP + j] + G1[j * RP + i]) + 2.0 * G2[i * RP + j]);
 }
 
 int launch_cov_finalize(mlmc_accum *a) {
@@ -572,7 +576,8 @@ int launch_cov_finalize(mlmc_accum *a) {
     const int R = vals ? a->Rout : a->R;
     hipLaunchKernelGGL(k_cov_finalize, dim3((R * R + 255) / 256, n_lc), dim3(256), 0, rt().stream, a->d_totals,
                        vals ? (const double *)nullptr : a->basis->d_scale, R,
-                       a->RP, a->int_width, a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n, a->d_out_nd);
+                       a->RP, a->int_width, a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n, a->d_out_nd,
+                       a->mean_only ? 1 : 0);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }

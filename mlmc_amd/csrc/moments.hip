@@ -747,7 +747,7 @@ __global__ void k_moments_finalize(const double *__restrict__ totals, const doub
                                    const double *__restrict__ T, int R, int RP, int Rout, int has_T, int64_t int_width,
                                    int n_lc, double *__restrict__ out_s, double *__restrict__ out_sp,
                                    const int64_t *__restrict__ counts, int n_levels, int64_t *__restrict__ out_n,
-                               double *__restrict__ out_nd) {
+                               double *__restrict__ out_nd, int mean_only) {
     const int lc = blockIdx.x;   // (level, comp)
     if (lc >= n_lc) return;
     if (lc == 0)
@@ -771,10 +771,12 @@ __global__ void k_moments_finalize(const double *__restrict__ totals, const doub
             for (int i = 0; i < R; ++i) {
                 const double ti = T[(int64_t)j * R + i] * scale_c[i];
                 s = __builtin_fma(ti, tot[i], s);
+                if (mean_only) continue;
                 double row = 0.0;
                 for (int k = 0; k < R; ++k) row = __builtin_fma(T[(int64_t)j * R + k] * scale_c[k], G[(int64_t)i * RP + k], row);
                 sp = __builtin_fma(ti, row, sp);
             }
+            if (mean_only) sp = __builtin_nan("");   // MLMC_MODE_MEAN_ONLY: the diff Gram matrix was not accumulated
         }
         out_s[(int64_t)lc * Rout + j] = s;
         out_sp[(int64_t)lc * Rout + j] = sp;
@@ -785,7 +787,7 @@ int launch_moments_finalize(mlmc_accum *a) {
     const int n_lc = a->n_levels * a->n_comp;
     hipLaunchKernelGGL(k_moments_finalize, dim3(n_lc), dim3(128), 0, rt().stream, a->d_totals, a->basis->d_scale,
                        a->basis->d_matrix, a->R, a->RP, a->Rout, a->basis->out_size > 0 ? 1 : 0, a->int_width, n_lc,
-                       a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n, a->d_out_nd);
+                       a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n, a->d_out_nd, a->mean_only ? 1 : 0);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }

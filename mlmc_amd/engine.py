@@ -58,7 +58,7 @@ class LevelAccumulator:
     MOMENTS = _lib.MODE_MOMENTS
     COV = _lib.MODE_COV
 
-    def __init__(self, moments_fn, n_levels, mode=_lib.MODE_MOMENTS, n_comp=1):
+    def __init__(self, moments_fn, n_levels, mode=_lib.MODE_MOMENTS, n_comp=1, mean_only=False):
         self._moments_fn = moments_fn if moments_fn is not None else _IdentityBasis()
         self.n_levels = int(n_levels)
         self.mode = int(mode)
@@ -67,8 +67,9 @@ class LevelAccumulator:
         self.rows_per_comp = r if mode == _lib.MODE_MOMENTS else r * r
         self.K = self.n_comp * self.rows_per_comp
         h = C.c_void_p()
-        _lib.check(_lib.lib().mlmc_accum_create(self._moments_fn._basis_handle(), self.n_levels, self.mode, self.n_comp,
-                                                C.byref(h)))
+        # mean_only: only the level means will be read; passes that exist for the variances alone are skipped (sp = NaN)
+        _lib.check(_lib.lib().mlmc_accum_create(self._moments_fn._basis_handle(), self.n_levels,
+                                                self.mode | (_lib.MODE_MEAN_ONLY if mean_only else 0), self.n_comp, C.byref(h)))
         self._h = h
         self._keepalive = []
 

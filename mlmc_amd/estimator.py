@@ -167,9 +167,10 @@ class Estimate:
         from .tool import simple_distribution
         if not isinstance(self._quantity.qtype, ScalarType):
             raise NotImplementedError("Currently, we only support ScalarType quantities")
-        cov_mat = qe.estimate_mean(qe.covariance(self._quantity, self._moments_fn)).mean
+        # only the means of the two estimates are used (the reference overwrites the variances with ones, :323)
+        cov_mat = qe.estimate_mean(qe.covariance(self._quantity, self._moments_fn), variance=False).mean
         moments_obj, info = simple_distribution.construct_ortogonal_moments(self._moments_fn, cov_mat, tol=orth_moments_tol)
-        est_moments = qe.estimate_mean(qe.moments(self._quantity, moments_obj)).mean
+        est_moments = qe.estimate_mean(qe.moments(self._quantity, moments_obj), variance=False).mean
         est_vars = np.ones(moments_obj.size)        # the reference discards the estimated variances (:323)
         moments_data = np.stack((est_moments, est_vars), axis=1)
         distr_obj = simple_distribution.SimpleDistribution(moments_obj, moments_data, domain=moments_obj.domain)

@@ -174,17 +174,17 @@ class _AccumulatorPool:
         self._items = collections.OrderedDict()
         self._capacity = capacity
 
-    def take(self, fn, n_levels, mode, n_comp):
-        key = (id(fn), n_levels, mode, n_comp)
+    def take(self, fn, n_levels, mode, n_comp, mean_only=False):
+        key = (id(fn), n_levels, mode, n_comp, bool(mean_only))
         item = self._items.pop(key, None)
         if item is not None:
             acc = item[0]
             acc.reset()
             return acc
-        return engine.LevelAccumulator(fn, n_levels, mode, n_comp=n_comp)
+        return engine.LevelAccumulator(fn, n_levels, mode, n_comp=n_comp, mean_only=mean_only)
 
-    def give(self, fn, n_levels, mode, n_comp, acc):
-        self._items[(id(fn), n_levels, mode, n_comp)] = (acc, fn)     # fn kept alive: its id stays unique
+    def give(self, fn, n_levels, mode, n_comp, acc, mean_only=False):
+        self._items[(id(fn), n_levels, mode, n_comp, bool(mean_only))] = (acc, fn)     # fn kept alive: its id stays unique
         while len(self._items) > self._capacity:
             _, (old, _) = self._items.popitem(last=False)
             old.close()
@@ -297,12 +297,14 @@ def _subsample_on_device(pair, params):
     return out_f, out_c
 
 
-def estimate_mean(quantity, group=None):
+def estimate_mean(quantity, group=None, variance=True):
     """MLMC mean estimator (reference: quantity_estimate.py:22-80).
 
     :param quantity: Quantity
     :param group: optional torch.distributed process group; when a group (or the default group) with more than one
                   rank is initialised every rank passes ITS shard of the samples and the level sums are all-reduced.
+    :param variance: False when only `.mean` / `.l_means` will be read (Estimate.construct_density): device passes that
+                  exist for the variances alone are skipped and the corresponding variances come back as NaN.
     :return: QuantityMean
     """
     cache_clear()
@@ -344,20 +346,20 @@ def estimate_mean(quantity, group=None):
         if pair is None or pair[0].shape[-1] == 0:               # empty chunk / every sample deselected
             if acc is None and pair is not None:
                 n_comp = pair[0].shape[0]
-                acc = _acc_pool.take(fn, n_levels, mode, n_comp)
+                acc = _acc_pool.take(fn, n_levels, mode, n_comp, mean_only=not variance)
             continue
         fine, coarse = pair
         if acc is None:
             n_comp = fine.shape[0]
             assert n_comp * rows_per_comp == quantity_vec_size
-            acc = _acc_pool.take(fn, n_levels, mode, n_comp)
+            acc = _acc_pool.take(fn, n_levels, mode, n_comp, mean_only=not variance)
         if n_comp == 1:
             fine, coarse = fine[0], (None if coarse is None else coarse[0])
         acc.push(chunk_spec.level_id, fine, coarse)
     if acc is None:
         raise Exception("All samples were masked")
     n_samples, n_rm_samples, sums, sums_sq = acc.finalize(group=group)
-    _acc_pool.give(fn, n_levels, mode, n_comp, acc)
+    _acc_pool.give(fn, n_levels, mode, n_comp, acc, mean_only=not variance)
     if int(np.sum(n_samples)) == 0:
         raise Exception("All samples were masked")
 

@@ -755,3 +755,39 @@ def test_maxent_cooperative_launch_matches_the_step_by_step_solver(hip):
             assert np.max(np.abs(got - mom)) < 50 * tol + 1e-7, (tag, np.max(np.abs(got - mom)))
         else:
             assert i1.success == 0 and i1.nit <= max_it
+
+
+@pytest.mark.parametrize("R", [8, 24, 64, 100])
+def test_mean_only_accumulators(hip, R):
+    """MLMC_MODE_MEAN_ONLY (what Estimate.construct_density asks for): the level sums equal those of the full estimate to
+    rounding, the skipped second moments come back as NaN; covariance (one Gram matrix instead of three) and
+    TransformedMoments (no diff-Gram pass)."""
+    from mlmc_amd import Legendre, TransformedMoments
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    levels = level_arrays([9001, 6000, 3500], [0.5, 0.07, 0.01], 1, 17)
+    fn = Legendre(R, dom)
+
+    def run(basis, mode, mean_only):
+        acc = LevelAccumulator(basis, len(levels), mode, mean_only=mean_only)
+        for l, (f, c) in enumerate(levels):
+            acc.push(l, f[0], None if c is None else c[0])
+        out = acc.finalize()
+        acc.close()
+        return out
+
+    n0, r0, s0, sp0 = run(fn, LevelAccumulator.COV, False)
+    n1, r1, s1, sp1 = run(fn, LevelAccumulator.COV, True)
+    assert np.array_equal(n0, n1) and np.array_equal(r0, r1)
+    scale = np.sqrt(np.abs(sp0) * n0[:, None]) + 1e-300
+    assert np.max(np.abs(s1 - s0) / scale) < 1e-12 and np.all(np.isnan(sp1))
+    if R <= 64:
+        rng = np.random.default_rng(R)
+        T = np.linalg.qr(rng.normal(size=(R, R)))[0][: max(2, R // 2)]
+        tm = TransformedMoments(fn, T)
+        n0, r0, s0, sp0 = run(tm, LevelAccumulator.MOMENTS, False)
+        n1, r1, s1, sp1 = run(tm, LevelAccumulator.MOMENTS, True)
+        assert np.array_equal(n0, n1) and np.array_equal(s0, s1) and np.all(np.isnan(sp1)) and np.all(np.isfinite(sp0))
+    # plain moments ignore the flag: their sum of squares costs nothing extra
+    a, b = run(fn, LevelAccumulator.MOMENTS, False), run(fn, LevelAccumulator.MOMENTS, True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
