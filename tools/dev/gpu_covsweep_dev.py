@@ -11,7 +11,7 @@ for l in range(L):
     x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
     data.append(((x + 0.07 * torch.sqrt(1e-4 + x.abs())).contiguous(), None if l == 0 else (x + 0.5 * torch.sqrt(1e-4 + x.abs())).contiguous()))
 for R in [int(r) for r in os.environ.get("RS", "64,4,5,8,10,16,20,24,32,40,48,64,96,128").split(",")]:
-    acc = LevelAccumulator(Legendre(R, (-3.719, 3.719)), L, LevelAccumulator.COV)
+    acc = LevelAccumulator(Legendre(R, (-3.719, 3.719)), L, LevelAccumulator.COV, mean_only=bool(os.environ.get("MEAN_ONLY")))
     for it in range(5):
         if it == 2:
             acc.kernel_time()
