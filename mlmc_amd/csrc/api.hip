@@ -348,8 +348,10 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
         const bool count = count_in_kernel && m == 0;
         int rc;
         if (a->mode == MLMC_MODE_MOMENTS) {
-            // chunks that stay valid until finalize (device memory, no staging / mask scratch) are gathered into one launch
-            const bool defer = mem_kind == MLMC_DEVICE && a->n_comp == 1;
+            // chunks that stay valid until finalize (device memory, no staging / mask scratch) are gathered into one launch;
+            // the components of a vector quantity share the chunk's mask scratch: they are gathered too, and launched
+            // together when the push ends (below)
+            const bool defer = mem_kind == MLMC_DEVICE || a->n_comp > 1;
             rc = launch_moments_accum(a, level, m, f_m, c_m, d_mask, n, count, defer);
             if (!rc && a->basis->out_size > 0 && !a->mean_only) rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, false, 1);
         } else if (a->basis->out_size > 0) {
@@ -381,6 +383,9 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
         }
         if (rc) return rc;
     }
+    // staged host data and the mask scratch are reused by the next push: their segments must be launched now
+    if (a->mode == MLMC_MODE_MOMENTS && (mem_kind == MLMC_HOST || a->n_comp > 1))
+        if (int rc = flush_moments(a)) return rc;
     return 0;
 }
 

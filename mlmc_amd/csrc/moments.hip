@@ -89,11 +89,11 @@ int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, dou
 // mask kernel for quantities with M > 1 components: a sample is dropped when ANY component of fine or
 // coarse is masked (mask_nan_samples reduces over axis 0, quantity_estimate.py:12).
 // ------------------------------------------------------------------------------------------
-__global__ void k_mask(BasisParams bp, const double *__restrict__ f, const double *__restrict__ c, int64_t n, int n_comp,
-                       uint8_t *__restrict__ mask, int64_t *__restrict__ counts) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_mask(BasisParams bp, const double *__restrict__ f, const double *__restrict__ c, int64_t n,
+                                              int n_comp, uint8_t *__restrict__ mask, int64_t *__restrict__ counts) {
+    __shared__ int red[4][2];
     int kept = 0, removed = 0;
-    if (i < n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         bool keep = true;
         for (int m = 0; m < n_comp; ++m) {
             bool k1, k2 = true;
@@ -102,21 +102,25 @@ __global__ void k_mask(BasisParams bp, const double *__restrict__ f, const doubl
             keep = keep && k1 && k2;
         }
         mask[i] = keep ? 1 : 0;
-        kept = keep;
-        removed = !keep;
+        kept += keep;
+        removed += !keep;
     }
     kept = wave_sum_i(kept);
     removed = wave_sum_i(removed);
-    if ((threadIdx.x & 63) == 0) {   // integer atomics: exact and order independent
-        atomicAdd((unsigned long long *)&counts[0], (unsigned long long)kept);
-        atomicAdd((unsigned long long *)&counts[1], (unsigned long long)removed);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = kept; red[threadIdx.x >> 6][1] = removed; }
+    __syncthreads();
+    if (threadIdx.x < 2) {   // one pair of integer atomics per block (exact, order independent); same-address atomics
+        // serialise in L2 at ~12 ns each, so they are kept to a few thousand per launch
+        const int v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd((unsigned long long *)&counts[threadIdx.x], (unsigned long long)v);
     }
 }
 
 int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64_t n, uint8_t *d_mask, int64_t *d_counts_level) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_mask, dim3((n + 255) / 256), dim3(256), 0, rt().stream, a->basis->p, d_f, d_c, n, a->n_comp, d_mask,
-                       d_counts_level);
+    const int64_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(k_mask, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, rt().stream, a->basis->p, d_f, d_c, n,
+                       a->n_comp, d_mask, d_counts_level);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -137,7 +141,7 @@ int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64
 #ifdef MLMC_PROF
 __device__ unsigned long long *g_prof;   // tools/dev/prof_moments.hip
 #endif
-constexpr int MAX_SEG = 8;
+constexpr int MAX_SEG = 16;
 constexpr int PRIO_SLICE_BITS = 15;   // 32768 cycles = 14 us at 2.4 GHz, a few trips of the sample loop
 struct Seg {
     const double *fine, *coarse;   // coarse == nullptr: level 0
