@@ -154,7 +154,7 @@ class Estimate:
         ranges = []
         for level_id in range(sample_storage.get_n_levels()):
             chunk_spec = next(sample_storage.chunks(n_samples=sample_storage.get_n_collected()[level_id]))
-            fine = np.squeeze(quantity.samples(chunk_spec)[..., 0])
+            fine = qe.fine_samples_for_device(quantity, chunk_spec)
             # NaN removal + np.percentile of the reference (:298-299) as one device call (exact radix select)
             ranges.append(engine.percentiles(fine, [100 * quantile, 100 * (1 - quantile)]))
         ranges = np.array(ranges)

@@ -272,16 +272,34 @@ def _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache):
     return item[0], item[1]
 
 
+def fine_samples_for_device(quantity, chunk_spec):
+    """Fine values of one chunk of `quantity` where the device wants them: a torch CUDA tensor when the tree is lowered
+    (stored rows resident or generated in HBM, nothing crosses PCIe), else the host array of the host-evaluated tree.
+    Used by Estimate.estimate_domain (percentiles of the fine samples)."""
+    plan = lowering.plan_for(quantity) if _device_tree_enabled() else None
+    if plan is None:
+        return np.squeeze(quantity.samples(chunk_spec)[..., 0])
+    storage_q = quantity.get_quantity_storage()
+    try:
+        n_collected = tuple(storage_q.n_collected())
+    except Exception:
+        n_collected = None
+    use_cache = _DeviceChunkCache.budget() > 0 and n_collected is not None
+    fine, _ = _chunk_for_device(quantity, plan, chunk_spec, n_collected, use_cache)
+    return fine
+
+
 def _subsample_on_device(pair, params):
     """Quantity.pick_samples (reference quantity.py:308-325) on the device: the chunk's share of the k-of-n sub-sample is
     drawn on the host (hypergeometric count, as in the reference), the `size` columns -- uniform with replacement,
     RNG.choice(chunk, size, axis=1) -- are gathered by mlmc_subsample_gather with a counter-based generator."""
-    import scipy.stats
     import torch
     from .. import _lib
     fine, coarse = pair
     n = fine.shape[-1]
-    size = int(scipy.stats.hypergeom(params._orig_n, params._orig_k, n).rvs(size=1, random_state=qmod.RNG)[0])
+    # scipy.stats.hypergeom(M = n_total, n = k, N = chunk).rvs() of the reference, drawn with the NumPy generator directly
+    # (building a frozen scipy distribution costs ~0.3 ms per chunk, more than the estimate itself)
+    size = int(qmod.RNG.hypergeometric(params._orig_k, params._orig_n - params._orig_k, min(n, params._orig_n)))
     seed = int(qmod.RNG.integers(0, 2 ** 63 - 1))
     if not isinstance(fine, torch.Tensor):                       # host chunk (over the cache budget): upload for the gather
         dev = torch.device("cuda", _lib_device())
