@@ -21,6 +21,7 @@ namespace mlmc {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int COV_BATCH = 64;
+__host__ __device__ constexpr int cov_batch(int T, bool wide, bool vals) { return (T <= 2 && !wide && !vals) ? 128 : 64; }
 constexpr int COV_LDS_STRIDE = 66;   // doubles per term row: == 2 (mod 32) -> ds_read_b64 fragments hit 32 distinct bank pairs
 
 // MODE 0: G0, G1, G2 (covariance mean + variance);  MODE 1: G = D^T D only (variance of transformed moments);
@@ -36,17 +37,21 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
                                                       const uint8_t *__restrict__ mask, int64_t n, int R,
                                                       double *__restrict__ partials, int64_t *__restrict__ pcounts) {
     constexpr int NT = 16 * T;                 // terms held in LDS
+    // samples per batch: 128 for the small tiles evaluated from raw samples (all four waves run recurrences, the
+    // barriers and the phase-1 latency are shared by twice the MFMA work), 64 otherwise
+    constexpr int BATCH = cov_batch(T, BI != BJ, VALS);
+    constexpr int STRIDE = BATCH + 2;          // doubles per term row: == 2 (mod 32) -> ds_read_b64 fragments hit 32 distinct bank pairs
     constexpr int NSL = 4 / T;                 // k-slices (waves sharing a row tile split the samples)
     constexpr int NG = (MODE == 0) ? (PAIR ? 3 : 2) : 1;
     constexpr bool WIDE = BI != BJ;            // two different term windows
     constexpr int TA = 64 * BI, TB = 64 * BJ;  // first term of the row / column window
     constexpr int N_EVAL = (BI > BJ ? TA : TB) + NT;   // terms the recurrence has to run through
     static_assert(T == 4 || (BI == 0 && BJ == 0), "term windows need T = 4");
-    __shared__ double lds_f[NT * COV_LDS_STRIDE];
-    __shared__ double lds_c[PAIR ? NT * COV_LDS_STRIDE : 1];
-    __shared__ double lds_fb[WIDE ? NT * COV_LDS_STRIDE : 1];              // column window (off-diagonal blocks)
-    __shared__ double lds_cb[(WIDE && PAIR) ? NT * COV_LDS_STRIDE : 1];
-    __shared__ int ldc[2][2];
+    __shared__ double lds_f[NT * STRIDE];
+    __shared__ double lds_c[PAIR ? NT * STRIDE : 1];
+    __shared__ double lds_fb[WIDE ? NT * STRIDE : 1];              // column window (off-diagonal blocks)
+    __shared__ double lds_cb[(WIDE && PAIR) ? NT * STRIDE : 1];
+    __shared__ int ldc[4][2];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int I = wave % T, kslice = wave / T;
@@ -58,28 +63,28 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
         for (int j = 0; j < T; ++j) acc[g][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
     // phase-1 role of this lane
-    const int n_eval_waves = PAIR ? 2 : 1;
+    const int n_eval_waves = PAIR ? BATCH / 32 : BATCH / 64;
     const bool evaluator = wave < n_eval_waves;
-    const int samp = PAIR ? (wave * 32 + (lane & 31)) : lane;   // sample slot in the batch
+    const int samp = PAIR ? (wave * 32 + (lane & 31)) : (wave * 64 + lane);   // sample slot in the batch
     const bool is_coarse = PAIR && (lane >> 5);
     const double *__restrict__ src = is_coarse ? coarse : fine;
     double *__restrict__ dst = is_coarse ? lds_c : lds_f;
     double *__restrict__ dst_b = WIDE ? (is_coarse ? lds_cb : lds_fb) : dst;
     int n_keep = 0, n_rm = 0;
 
-    const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
+    const int64_t n_batches = (n + BATCH - 1) / BATCH;
     int64_t batch = blockIdx.x;
     double xv = 0.0;
     uint8_t mv = 1;
     if (!VALS && evaluator && batch < n_batches) {
-        int64_t idx = batch * COV_BATCH + samp;
+        int64_t idx = batch * BATCH + samp;
         if (idx < n) { xv = src[idx]; if (mask) mv = mask[idx]; }
     }
     for (; batch < n_batches; batch += gridDim.x) {
         // ---------------- phase 1: moment values of this batch -> LDS ----------------
         if (VALS) {
             if (evaluator) {
-                const int64_t idx = batch * COV_BATCH + samp;
+                const int64_t idx = batch * BATCH + samp;
                 const bool valid = idx < n;
                 const double *__restrict__ row = src + idx * (int64_t)R;
                 bool keep = valid && (!mask || mask[idx] != 0);
@@ -89,10 +94,10 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
                     keep = keep && (other != 0);
                 }
                 if (!is_coarse) { n_keep += (int)keep; n_rm += (int)(valid && !keep); }
-                for (int i = 0; i < NT; ++i) dst[i * COV_LDS_STRIDE + samp] = (keep && i < R) ? row[i] : 0.0;
+                for (int i = 0; i < NT; ++i) dst[i * STRIDE + samp] = (keep && i < R) ? row[i] : 0.0;
             }
         } else if (evaluator) {
-            const int64_t idx = batch * COV_BATCH + samp;
+            const int64_t idx = batch * BATCH + samp;
             const bool valid = idx < n;
             bool keep;
             double t = transform_value(bp, xv, keep);
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
             }
             if (!is_coarse) { n_keep += (int)keep; n_rm += (int)(valid && !keep); }
             // prefetch the next batch's value
-            const int64_t nidx = (batch + gridDim.x) * COV_BATCH + samp;
+            const int64_t nidx = (batch + gridDim.x) * BATCH + samp;
             if (nidx < n) { xv = src[nidx]; if (mask) mv = mask[nidx]; }
             TermGen<KIND> g;
             g.init(keep ? t : 0.0, keep ? 1.0 : 0.0, bp);
@@ -112,8 +117,8 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
 #pragma unroll
             for (int i = 0; i < N_EVAL; ++i) {
                 const double q = g.next(i);
-                if (i >= TA && i < TA + NT) dst[(i - TA) * COV_LDS_STRIDE + samp] = q;
-                if (WIDE && i >= TB && i < TB + NT) dst_b[(i - TB) * COV_LDS_STRIDE + samp] = q;
+                if (i >= TA && i < TA + NT) dst[(i - TA) * STRIDE + samp] = q;
+                if (WIDE && i >= TB && i < TB + NT) dst_b[(i - TB) * STRIDE + samp] = q;
             }
         }
         __syncthreads();
@@ -121,13 +126,13 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
         const int arow = 16 * I + (lane & 15);
         // fixed trip count -> fully unrolled: the compiler hoists the next steps' LDS reads above the MFMAs
 #pragma unroll
-        for (int kk = 0; kk < COV_BATCH / 4 / NSL; ++kk) {
+        for (int kk = 0; kk < BATCH / 4 / NSL; ++kk) {
             const int ks = kslice + kk * NSL;
             const int col = 4 * ks + (lane >> 4);
-            double fa = lds_f[arow * COV_LDS_STRIDE + col];
+            double fa = lds_f[arow * STRIDE + col];
             double da = fa, sa = fa;
             if (PAIR) {
-                double ca = lds_c[arow * COV_LDS_STRIDE + col];
+                double ca = lds_c[arow * STRIDE + col];
                 da = fa - ca;
                 sa = fa + ca;
             }
@@ -135,10 +140,10 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
 #pragma unroll
             for (int J = 0; J < T; ++J) {
                 const int brow = 16 * J + (lane & 15);
-                double fb = (WIDE ? lds_fb : lds_f)[brow * COV_LDS_STRIDE + col];
+                double fb = (WIDE ? lds_fb : lds_f)[brow * STRIDE + col];
                 double db = fb, sb = fb;
                 if (PAIR) {
-                    double cb = (WIDE ? lds_cb : lds_c)[brow * COV_LDS_STRIDE + col];
+                    double cb = (WIDE ? lds_cb : lds_c)[brow * STRIDE + col];
                     db = fb - cb;
                     sb = fb + cb;
                 }
@@ -185,10 +190,10 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
     if (pcounts) {
         n_keep = wave_sum_i(n_keep);
         n_rm = wave_sum_i(n_rm);
-        if (lane == 0 && wave < 2) { ldc[wave][0] = n_keep; ldc[wave][1] = n_rm; }
+        if (lane == 0) { ldc[wave][0] = n_keep; ldc[wave][1] = n_rm; }      // non-evaluator waves carry zeros
         __syncthreads();
         if (threadIdx.x < 2) {
-            int v = ldc[0][threadIdx.x] + (PAIR ? ldc[1][threadIdx.x] : 0);
+            const int v = ldc[0][threadIdx.x] + ldc[1][threadIdx.x] + ldc[2][threadIdx.x] + ldc[3][threadIdx.x];
             pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = v;
         }
     }
@@ -500,7 +505,8 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     const int NG = gram_mode == 0 ? 3 : 1;
     const int NB = (R + 63) / 64;          // 64 x 64 output blocks per dimension
     const bool pair = d_c != nullptr;
-    const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
+    const int64_t bsz = cov_batch(T, false, false);
+    const int64_t n_batches = (n + bsz - 1) / bsz;
     const size_t width = (size_t)NG * NT * NT;
     const BasisParams &bp = a->basis->p;
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0);
