@@ -107,6 +107,12 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
  * Outputs in host or device memory (device: for an RCCL all-reduce over ranks before the host reads them).
  * Synchronises the stream; idempotent. */
 int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, double *sp, int mem_kind);
+/* reset + push of n_chunks chunks + finalize in one call (one host round trip per estimate): chunk k is
+ * (levels[k], fine[k], coarse[k] or NULL, n[k]); all chunk buffers of one kind (mem_kind).  Results as mlmc_accum_finalize
+ * with MLMC_HOST outputs. */
+int mlmc_accum_estimate(mlmc_accum *a, int32_t n_chunks, const int32_t *levels, const double *const *fine,
+                        const double *const *coarse, const int64_t *n_samples, int mem_kind, int64_t *n, int64_t *n_rm,
+                        double *s, double *sp);
 /* Same results in ONE fp64 buffer [n(L) | n_rm(L) | s(L*K) | sp(L*K)] (counts as exact doubles): a single packed
  * all-reduce (RCCL) then carries everything a multi-GPU estimate has to exchange.  With MLMC_DEVICE the call is
  * asynchronous (stream-ordered); with MLMC_HOST it synchronises. */

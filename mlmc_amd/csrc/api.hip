@@ -439,6 +439,16 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
     return 0;
 }
 
+int mlmc_accum_estimate(mlmc_accum *a, int32_t n_chunks, const int32_t *levels, const double *const *fine,
+                        const double *const *coarse, const int64_t *n_samples, int mem_kind, int64_t *n, int64_t *n_rm,
+                        double *s, double *sp) {
+    if (!a || n_chunks < 0 || (n_chunks > 0 && (!levels || !fine || !n_samples))) return fail("mlmc_accum_estimate: null argument");
+    if (int rc = mlmc_accum_reset(a)) return rc;
+    for (int k = 0; k < n_chunks; ++k)
+        if (int rc = mlmc_accum_push(a, levels[k], fine[k], coarse ? coarse[k] : nullptr, n_samples[k], mem_kind)) return rc;
+    return mlmc_accum_finalize(a, n, n_rm, s, sp, MLMC_HOST);
+}
+
 int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind) {
     if (need_runtime()) return 1;
     if (!a || !packed) return fail("mlmc_accum_finalize_packed: null argument");

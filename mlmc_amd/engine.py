@@ -101,6 +101,27 @@ class LevelAccumulator:
         _lib.check(_lib.lib().mlmc_accum_push(self._h, int(level), _lib.ptr(fine), _lib.ptr(coarse), int(n),
                                               _lib.mem_kind(fine)))
 
+    def estimate(self, chunks):
+        """reset + push + finalize in one call of the C ABI (`mlmc_accum_estimate`): chunks = [(level, fine, coarse | None)]
+        of torch CUDA tensors, shape [n] ([M, n] for vector quantities).  Single-process estimates only (no all-reduce).
+        -> n[L], n_rm[L], s[L, K], sp[L, K]"""
+        k = len(chunks)
+        levels = (C.c_int32 * k)(*[int(c[0]) for c in chunks])
+        fine = (C.c_void_p * k)(*[c[1].data_ptr() for c in chunks])
+        coarse = (C.c_void_p * k)(*[None if c[2] is None else c[2].data_ptr() for c in chunks])
+        ns = (C.c_int64 * k)(*[int(c[1].shape[-1]) for c in chunks])
+        L, K = self.n_levels, self.K
+        bufs = getattr(self, "_est_out", None)
+        if bufs is None:
+            bufs = self._est_out = (np.empty(L, dtype=np.int64), np.empty(L, dtype=np.int64),
+                                    np.empty((L, K), dtype=np.float64), np.empty((L, K), dtype=np.float64))
+        self._keepalive = list(chunks)
+        n, n_rm, s, sp = bufs
+        _lib.check(_lib.lib().mlmc_accum_estimate(self._h, k, levels, fine, coarse, ns, _lib.DEVICE, _lib.ptr(n), _lib.ptr(n_rm),
+                                                  _lib.ptr(s), _lib.ptr(sp)))
+        self._keepalive = []
+        return n.copy(), n_rm.copy(), s.copy(), sp.copy()
+
     def finalize(self, group=None, reduce=True):
         """-> n[L], n_rm[L] (int64), s[L, K], sp[L, K] (float64); all-reduced over ranks when distributed."""
         L, K = self.n_levels, self.K

@@ -791,3 +791,24 @@ def test_mean_only_accumulators(hip, R):
     # plain moments ignore the flag: their sum of squares costs nothing extra
     a, b = run(fn, LevelAccumulator.MOMENTS, False), run(fn, LevelAccumulator.MOMENTS, True)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_estimate_in_one_call(hip):
+    """mlmc_accum_estimate (reset + pushes + finalize in one C call) == the three-step protocol, bit for bit."""
+    import torch
+    from mlmc_amd import Legendre
+    from mlmc_amd.engine import LevelAccumulator
+    dev = torch.device("cuda", 0)
+    levels = level_arrays([30001, 20000, 9000], [0.5, 0.07, 0.01], 1, 23)
+    chunks = [(l, torch.from_numpy(f[0]).to(dev), None if c is None else torch.from_numpy(c[0]).to(dev))
+              for l, (f, c) in enumerate(levels)]
+    torch.cuda.synchronize()
+    for mode, R in ((LevelAccumulator.MOMENTS, 13), (LevelAccumulator.COV, 9)):
+        acc = LevelAccumulator(Legendre(R, (-3.7190164854556804, 3.7190164854556804)), 3, mode)
+        for l, f, c in chunks:
+            acc.push(l, f, c)
+        ref = acc.finalize()
+        for _ in range(2):                       # repeated use of the same accumulator
+            got = acc.estimate(chunks)
+            assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+        acc.close()
