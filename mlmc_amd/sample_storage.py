@@ -114,7 +114,7 @@ class Memory(SampleStorage):
     def set_level_samples(self, level_id, fine, coarse=None, sample_ids=None):
         """Append a block of samples: fine / coarse arrays [N] or [N, M] (coarse ignored / zero at level 0)."""
         fine = np.asarray(fine, dtype=np.float64)
-        fine = fine.reshape(fine.shape[0], -1)
+        fine = fine.reshape(fine.shape[0], int(np.prod(fine.shape[1:])))     # also for a block without samples
         coarse = np.zeros_like(fine) if coarse is None else np.asarray(coarse, dtype=np.float64).reshape(fine.shape)
         block = np.stack([fine, coarse], axis=1)                # [N, 2, M]
         self._append(level_id, block, sample_ids if sample_ids is not None else

@@ -689,3 +689,56 @@ def test_device_tree_against_reference_golden(hip):
                 assert np.allclose(got, want, rtol=1e-13, atol=1e-15), (name, np.max(np.abs(got - want)))
             else:
                 assert np.array_equal(got, want, equal_nan=True), (name, np.nanmax(np.abs(got - want)))
+
+
+def test_device_tree_edge_sizes(hip):
+    """Chunk sizes around the kernel's block / compaction granularity (1, 255, 256, 257, 511, 513, 4095, 4097, 8193), a
+    selection that keeps nothing / everything, and a level without samples."""
+    import torch
+    from mlmc_amd import Legendre
+    from mlmc_amd.quantity import lowering, quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.quantity.quantity_spec import QuantitySpec
+    from mlmc_amd.sample_storage import Memory
+    from tests.test_lowering import host_chunk
+    spec = [QuantitySpec(name="q", unit="", shape=(2, 1), times=[1], locations=['0'])]
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    for n in (1, 255, 256, 257, 511, 513, 4095, 4097, 8193):
+        st = Memory()
+        st.save_global_data(result_format=spec, level_parameters=[[0.5], [0.1]])
+        f = rng.normal(size=(n, 2))
+        st.set_level_samples(0, f, None)
+        st.set_level_samples(1, f + 1.0, f + 1.01)
+        st.save_n_ops([(0, (1.0, 1)), (1, (1.0, 1))])
+        root = make_root_quantity(st, spec)['q'][1]['0']
+        x, y = root[0], root[1]
+        trees = {"arith": x * y + 0.5, "some": (x - y).select(x > 0.3), "none": x.select(x > 1e9), "all": root.select(x > -1e9)}
+        for name, q in trees.items():
+            plan = lowering.lower(q)
+            for chunk in st.chunks():
+                stored = st.sample_pairs_level(chunk)
+                want = host_chunk(q, chunk)
+                rows = [torch.from_numpy(np.ascontiguousarray(stored[r])).to(dev) for r in plan.in_rows]
+                torch.cuda.synchronize()
+                fo, co, _ = plan.evaluate(rows, has_coarse=(stored.shape[-1] == 2), n=stored.shape[1], sync=True)
+                got = fo.cpu().numpy()[:, :, None]
+                if co is not None:
+                    got = np.concatenate([got, co.cpu().numpy()[:, :, None]], axis=2)
+                assert got.shape == want.shape and np.array_equal(got, want), (n, name, chunk.level_id)
+    # a level that has no samples at all, and a selection that empties one level
+    st = Memory()
+    st.save_global_data(result_format=spec, level_parameters=[[0.5], [0.1], [0.02]])
+    f = rng.normal(size=(500, 2))
+    st.set_level_samples(0, f, None)
+    st.set_level_samples(1, np.empty((0, 2)), np.empty((0, 2)))
+    st.set_level_samples(2, f[:300] + 5.0, f[:300] + 5.01)
+    st.save_n_ops([(0, (1.0, 1)), (1, (1.0, 1)), (2, (1.0, 1))])
+    x = make_root_quantity(st, spec)['q'][1]['0'][0]
+    fn = Legendre(4, (-4.0, 8.0))
+    qe.device_cache_clear()
+    m = qe.estimate_mean(qe.moments(x, fn))
+    assert m.n_samples.tolist() == [500, 0, 300]
+    m = qe.estimate_mean(qe.moments(x.select(x < 1.0), fn))          # level 2 lives around 5: nothing selected there
+    assert m.n_samples[2] == 0 and m.n_samples[0] > 400
+    qe.device_cache_clear()
