@@ -339,7 +339,6 @@ def tree_bench(args, cfg, world, rank, dev, dist):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU leg: the same tree evaluated the way the reference does it (NumPy closures over [M, n, 2] chunks,
         # mlmc/quantity/quantity.py) on a bounded sample, and the parity of the device rows against it
-        from mlmc_amd.quantity.quantity_spec import ChunkSpec
         m = 2_000_000
         host_rows = np.stack([stored[1][0][:m].cpu().numpy(), stored[1][1][:m].cpu().numpy()])     # [2, m, 2]
         st2 = Memory()

@@ -8,7 +8,6 @@ import numpy as np
 
 from . import engine
 from .quantity import quantity_estimate as qe
-from .quantity.quantity_spec import ChunkSpec
 from .quantity.quantity_types import ScalarType
 
 
