@@ -208,6 +208,8 @@ def main():
     step_kernel_s = (kt[0] / 1e3) / args.steps
     achieved_tflops = flops / step_kernel_s / 1e12 if step_kernel_s > 0 else 0.0
     traffic, traffic_src = pmc_traffic_per_launch(args.config, kname, n_l, L, kt[1] // max(args.steps, 1))
+    if cfg.get("basis") == "Spline":
+        kname = "k_spline_accum"     # sparse LDS-atomic kernel: <= 8 of the R sums touched per sample, no dense flop count applies
     roofline = {
         "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -218,6 +220,9 @@ def main():
                 "frac": round(achieved_tflops / alu_peak, 4), "alg_flops_per_step": int(flops)},
     }
 
+    if cfg.get("basis") == "Spline":
+        roofline.pop("alu")
+        roofline["note"] = "ds_add_f64 (LDS atomic) bound: 8 updates per sample pair into per-wave copies of the 2 R sums"
     out = {
         "metric": "moment-evals/sec (samples x n_moments)", "value": value, "unit": "moment-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
