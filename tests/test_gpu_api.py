@@ -742,3 +742,41 @@ def test_device_tree_edge_sizes(hip):
     m = qe.estimate_mean(qe.moments(x.select(x < 1.0), fn))          # level 2 lives around 5: nothing selected there
     assert m.n_samples[2] == 0 and m.n_samples[0] > 400
     qe.device_cache_clear()
+
+
+def test_north_star_size_properties(hip):
+    """BASELINE's north-star size -- 10^8 samples per level x 64 Legendre moments -- through the whole API on samples
+    generated in HBM: size-independent properties (the oracle cannot run at this size): P0 sums are exact counts,
+    mean[0] == 1 and var[0] == 0 exactly, re-chunking the same samples changes nothing beyond rounding, the removed
+    counts equal the number of out-of-domain samples of a direct device count."""
+    import torch
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.sim.synth_device import SynthDeviceStorage
+    n = 100_000_000
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    res = {}
+    for tag, chunk in (("one", None), ("chunked", 30_000_000)):
+        qe.device_cache_clear()
+        st = SynthDeviceStorage([[0.1], [0.02]], [n, n], chunk_size=chunk)
+        q = make_root_quantity(st, st.load_result_format())['length'][1]['10'][0]
+        qm = qe.estimate_mean(qe.moments(q, Legendre(64, dom)))
+        res[tag] = qm
+        assert qm.mean[0] == 1.0 and qm.var[0] == 0.0
+        assert np.all(qm.n_samples + qm.n_rm_samples == n)
+    a, b = res["one"], res["chunked"]
+    assert a.n_samples.tolist() == b.n_samples.tolist() and a.n_rm_samples.tolist() == b.n_rm_samples.tolist()
+    assert close(b.l_means, a.l_means, scale=1.0, tol=1e-11) and close(b.l_vars, a.l_vars, scale=np.max(a.l_vars), tol=1e-11)
+    # removed samples of level 0: direct count of |x| outside the domain on the device
+    st = SynthDeviceStorage([[0.1], [0.02]], [n, n])
+    row = st.device_row(next(st.chunks(level_id=0)), 0)
+    hip.check(hip.lib().mlmc_synchronize())
+    x = row[:, 0]
+    t = (x - dom[0]) * (2.0 / max(dom[1] - dom[0], 1e-15)) + (-1.0)
+    outside = int(((t < -1.0) | (t > 1.0)).sum().item())
+    assert outside == int(a.n_rm_samples[0]) and 0 < outside < n // 100
+    qe.device_cache_clear()
+    del row, x, t
+    torch.cuda.empty_cache()
