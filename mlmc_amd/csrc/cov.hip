@@ -276,6 +276,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
             }
         }
         __syncthreads();
+        __builtin_amdgcn_s_setprio(1);   // MFMA phase: issue ahead of the other workgroup's recurrence phase (+1 % MFMA time)
 #pragma unroll
         for (int ks = 0; ks < COV_BATCH / 4; ++ks) {
             const int col = 4 * ks + (lane >> 4);
@@ -319,6 +320,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
                     accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[sym_i(W, t)], d[sym_j(W, t)], accs[0][t], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
 
