@@ -780,3 +780,37 @@ def test_north_star_size_properties(hip):
     qe.device_cache_clear()
     del row, x, t
     torch.cuda.empty_cache()
+
+
+def test_device_tree_many_stored_rows(hip):
+    """More than 64 referenced stored rows: the row pointer table goes through device memory instead of the kernel
+    arguments (two evaluations back to back: the second overwrites the table after the stream has drained)."""
+    import torch
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.quantity.quantity_spec import QuantitySpec
+    from mlmc_amd.sample_storage import Memory
+    from tests.test_lowering import host_chunk
+    spec = [QuantitySpec(name="q", unit="", shape=(90, 1), times=[1], locations=['0'])]
+    rng = np.random.default_rng(8)
+    st = Memory()
+    st.save_global_data(result_format=spec, level_parameters=[[0.5], [0.1]])
+    f = rng.normal(size=(700, 90))
+    st.set_level_samples(0, f, None)
+    st.set_level_samples(1, f + 1.0, f + 1.01)
+    st.save_n_ops([(0, (1.0, 1)), (1, (1.0, 1))])
+    root = make_root_quantity(st, spec)['q'][1]['0']
+    q = root * 2.0 - 1.0
+    plan = lowering.lower(q)
+    assert len(plan.in_rows) == 90 and plan.n_out == 90
+    dev = torch.device("cuda", 0)
+    for rep in range(2):
+        for chunk in st.chunks():
+            stored = st.sample_pairs_level(chunk)
+            rows = [torch.from_numpy(np.ascontiguousarray(stored[r])).to(dev) for r in plan.in_rows]
+            torch.cuda.synchronize()
+            fo, co, _ = plan.evaluate(rows, has_coarse=(stored.shape[-1] == 2), n=stored.shape[1], sync=True)
+            got = fo.cpu().numpy()[:, :, None]
+            if co is not None:
+                got = np.concatenate([got, co.cpu().numpy()[:, :, None]], axis=2)
+            assert np.array_equal(got, host_chunk(q, chunk))
