@@ -3,8 +3,9 @@
 // Reference: Estimate.estimate_domain (mlmc/estimator.py:275-302) removes NaNs from the fine samples of a level and
 // calls np.percentile(fine, [100 q, 100 (1 - q)]) (NumPy "linear" method: interpolation between the two neighbouring
 // order statistics).  Here the two neighbours are found exactly by a most-significant-digit radix select on an
-// order-preserving 64-bit key (11-bit digits, per-block LDS histograms, 6 passes over the data), and the
+// order-preserving 64-bit key (11-bit digits, per-block LDS histograms, 6 passes over the data for all ranks), and the
 // interpolation is done with NumPy's own formula, so the result is bit-identical to np.percentile.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -21,30 +22,42 @@ __device__ __forceinline__ unsigned long long order_key(double x) {
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);   // monotone in x for all non-NaN values (-0.0 < +0.0)
 }
 
-// histogram of the digit at `shift` over the keys whose bits above (shift + SEL_BITS) equal `prefix`
-__global__ __launch_bounds__(256) void k_select_hist(const double *__restrict__ x, int64_t n, unsigned long long prefix,
-                                                     int shift, int width, int first, unsigned int *__restrict__ hist,
-                                                     unsigned long long *__restrict__ n_valid) {
-    __shared__ unsigned int lh[SEL_BINS];
-    for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x) lh[i] = 0;
+constexpr int SEL_MAX_PREFIX = 4;   // distinct key prefixes followed in one pass (LDS: 4 x 2048 counters = 32 KB)
+
+struct SelPrefixes {
+    unsigned long long prefix[SEL_MAX_PREFIX];
+    int n;
+};
+
+// One pass of the most-significant-digit radix select for up to SEL_MAX_PREFIX targets at once: histogram of the digit
+// at `shift` over the keys whose higher bits equal prefix[t] (first pass: no prefix, a single histogram of all non-NaN
+// values -- its total is the number of valid values).
+__global__ __launch_bounds__(256) void k_select_hist(const double *__restrict__ x, int64_t n, SelPrefixes pf, int shift,
+                                                     int width, int first, unsigned int *__restrict__ hist) {
+    __shared__ unsigned int lh[SEL_MAX_PREFIX][SEL_BINS];
+    for (int i = threadIdx.x; i < SEL_MAX_PREFIX * SEL_BINS; i += blockDim.x) (&lh[0][0])[i] = 0;
     __syncthreads();
     const int hi_shift = shift + width;
     const unsigned mask = (1u << width) - 1u;
-    unsigned long long valid = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double v = x[i];
         if (v != v) continue;                       // NaNs are removed (estimator.py:298)
-        ++valid;
         const unsigned long long key = order_key(v);
-        const bool match = first || ((key >> hi_shift) == prefix);
-        if (match) atomicAdd(&lh[(unsigned)(key >> shift) & mask], 1u);
+        const unsigned digit = (unsigned)(key >> shift) & mask;
+        if (first) {
+            atomicAdd(&lh[0][digit], 1u);
+        } else {
+            const unsigned long long hi = key >> hi_shift;
+#pragma unroll
+            for (int t = 0; t < SEL_MAX_PREFIX; ++t)
+                if (t < pf.n && hi == pf.prefix[t]) atomicAdd(&lh[t][digit], 1u);
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SEL_BINS; i += blockDim.x)
-        if (lh[i]) atomicAdd(&hist[i], lh[i]);
-    if (first) {   // exact integer count, order independent
-        for (int off = 32; off >= 1; off >>= 1) valid += __shfl_xor(valid, off, 64);
-        if ((threadIdx.x & 63) == 0 && valid) atomicAdd(n_valid, valid);
+    const int n_hist = first ? 1 : pf.n;
+    for (int i = threadIdx.x; i < n_hist * SEL_BINS; i += blockDim.x) {
+        const unsigned v = (&lh[0][0])[i];
+        if (v) atomicAdd(&hist[i], v);
     }
 }
 
@@ -55,46 +68,74 @@ static double key_to_double(unsigned long long key) {
     return d;
 }
 
-// k-th smallest (0-based) non-NaN value of d_x[0..n)
-static int select_kth(const double *d_x, int64_t n, int64_t k, unsigned int *d_hist, unsigned long long *d_nvalid, double *out,
-                      int64_t *n_valid_out) {
+// The ranks[0..nr) smallest (0-based, ascending or not) non-NaN values of d_x[0..n): six passes over the data in total
+// (one shared top-digit pass, then five passes that follow all distinct prefixes together).  ranks may be filled in
+// after the first pass: `plan(nv)` is called with the number of valid values and returns them.
+template <typename Plan>
+static int select_ranks(const double *d_x, int64_t n, Plan plan, std::vector<int64_t> &ranks, std::vector<double> &values,
+                        int64_t *n_valid_out) {
     hipStream_t st = rt().stream;
-    std::vector<unsigned int> hist(SEL_BINS);
-    unsigned long long prefix = 0;
+    static unsigned int *d_hist = nullptr;
+    static unsigned int *h_hist = nullptr;          // pinned
+    if (!d_hist) {
+        MLMC_HIP_CHECK(hipMalloc(&d_hist, sizeof(unsigned int) * SEL_MAX_PREFIX * SEL_BINS));
+        MLMC_HIP_CHECK(hipHostMalloc((void **)&h_hist, sizeof(unsigned int) * SEL_MAX_PREFIX * SEL_BINS, hipHostMallocDefault));
+    }
     int blocks = rt().n_cu * 4;
     const int64_t want = (n + 255) / 256;
     if (want < blocks) blocks = (int)(want > 0 ? want : 1);
     // digits from the top: bits [53, 64), [42, 53), [31, 42), [20, 31), [9, 20), then the last 9 bits
     const int shifts[6] = {53, 42, 31, 20, 9, 0};
+    std::vector<unsigned long long> prefix;   // per rank
+    std::vector<int64_t> k;                   // remaining rank inside the prefix
     for (int pass = 0; pass < 6; ++pass) {
         const int shift = shifts[pass];
         const int width = (pass == 5) ? 9 : SEL_BITS;
-        MLMC_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * SEL_BINS, st));
-        if (pass == 0) MLMC_HIP_CHECK(hipMemsetAsync(d_nvalid, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_select_hist, dim3(blocks), dim3(256), 0, st, d_x, n, prefix, shift, width, pass == 0 ? 1 : 0, d_hist, d_nvalid);
-        MLMC_HIP_CHECK(hipGetLastError());
-        MLMC_HIP_CHECK(hipMemcpyAsync(hist.data(), d_hist, sizeof(unsigned int) * SEL_BINS, hipMemcpyDeviceToHost, st));
-        if (pass == 0) {
-            unsigned long long nv = 0;
-            MLMC_HIP_CHECK(hipMemcpyAsync(&nv, d_nvalid, sizeof(nv), hipMemcpyDeviceToHost, st));
-            MLMC_HIP_CHECK(hipStreamSynchronize(st));
-            if (n_valid_out) *n_valid_out = (int64_t)nv;
-            if (k < 0 || (unsigned long long)k >= nv) return fail("order statistic index out of range");
-        } else {
-            MLMC_HIP_CHECK(hipStreamSynchronize(st));
-        }
-        int64_t cum = 0;
-        int digit = -1;
         const int nbins = 1 << width;
-        for (int b = 0; b < nbins; ++b) {
-            if (k < cum + (int64_t)hist[b]) { digit = b; break; }
-            cum += hist[b];
+        // distinct prefixes of this pass, SEL_MAX_PREFIX at a time
+        std::vector<unsigned long long> uniq;
+        if (pass == 0) uniq.push_back(0);
+        else
+            for (unsigned long long p : prefix)
+                if (std::find(uniq.begin(), uniq.end(), p) == uniq.end()) uniq.push_back(p);
+        std::vector<std::vector<unsigned int>> hists(uniq.size());
+        for (size_t g0 = 0; g0 < uniq.size(); g0 += SEL_MAX_PREFIX) {
+            SelPrefixes pf;
+            pf.n = (int)std::min<size_t>(SEL_MAX_PREFIX, uniq.size() - g0);
+            for (int t = 0; t < SEL_MAX_PREFIX; ++t) pf.prefix[t] = t < pf.n ? uniq[g0 + t] : 0;
+            MLMC_HIP_CHECK(hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * pf.n * SEL_BINS, st));
+            hipLaunchKernelGGL(k_select_hist, dim3(blocks), dim3(256), 0, st, d_x, n, pf, shift, width, pass == 0 ? 1 : 0, d_hist);
+            MLMC_HIP_CHECK(hipGetLastError());
+            MLMC_HIP_CHECK(hipMemcpyAsync(h_hist, d_hist, sizeof(unsigned int) * pf.n * SEL_BINS, hipMemcpyDeviceToHost, st));
+            MLMC_HIP_CHECK(hipStreamSynchronize(st));
+            for (int t = 0; t < pf.n; ++t) hists[g0 + t].assign(h_hist + (size_t)t * SEL_BINS, h_hist + (size_t)t * SEL_BINS + nbins);
         }
-        if (digit < 0) return fail("radix select: inconsistent histogram");
-        k -= cum;
-        prefix = (prefix << width) | (unsigned long long)digit;
+        if (pass == 0) {
+            int64_t nv = 0;
+            for (unsigned int c : hists[0]) nv += c;
+            if (n_valid_out) *n_valid_out = nv;
+            ranks = plan(nv);
+            for (int64_t r : ranks)
+                if (r < 0 || r >= nv) return fail("order statistic index out of range");
+            prefix.assign(ranks.size(), 0);
+            k = ranks;
+        }
+        for (size_t r = 0; r < ranks.size(); ++r) {
+            const size_t u = pass == 0 ? 0 : (size_t)(std::find(uniq.begin(), uniq.end(), prefix[r]) - uniq.begin());
+            const std::vector<unsigned int> &h = hists[u];
+            int64_t cum = 0;
+            int digit = -1;
+            for (int bin = 0; bin < nbins; ++bin) {
+                if (k[r] < cum + (int64_t)h[bin]) { digit = bin; break; }
+                cum += h[bin];
+            }
+            if (digit < 0) return fail("radix select: inconsistent histogram");
+            k[r] -= cum;
+            prefix[r] = (prefix[r] << width) | (unsigned long long)digit;
+        }
     }
-    *out = key_to_double(prefix);
+    values.resize(ranks.size());
+    for (size_t r = 0; r < ranks.size(); ++r) values[r] = key_to_double(prefix[r]);
     return 0;
 }
 
@@ -107,6 +148,8 @@ extern "C" int mlmc_percentiles(const double *x, int64_t n, const double *q_perc
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!x || !q_percent || !out || nq <= 0) return fail("mlmc_percentiles: bad argument");
     if (n <= 0) return fail("mlmc_percentiles: empty input");
+    for (int i = 0; i < nq; ++i)
+        if (!(q_percent[i] >= 0.0 && q_percent[i] <= 100.0)) return fail("mlmc_percentiles: percentiles must be in [0, 100]");
     hipStream_t st = rt().stream;
     double *d_x = nullptr;
     bool own = false;
@@ -118,39 +161,36 @@ extern "C" int mlmc_percentiles(const double *x, int64_t n, const double *q_perc
     } else {
         d_x = const_cast<double *>(x);
     }
-    unsigned int *d_hist = nullptr;
-    if (hipMalloc(&d_hist, sizeof(unsigned int) * SEL_BINS + 64) != hipSuccess) {
-        if (own) (void)hipFree(d_x);
-        return fail("mlmc_percentiles: hipMalloc failed");
-    }
-    unsigned long long *d_nvalid = (unsigned long long *)(d_hist + SEL_BINS);
-    int rc = 0;
+    // NumPy: q = percent / 100 ; virtual index = (n - 1) * q ; linear interpolation between the neighbours
+    std::vector<double> gamma(nq);
+    auto plan = [&](int64_t nv) {
+        std::vector<int64_t> ranks;
+        for (int i = 0; i < nq; ++i) {
+            const double vi = (double)(nv - 1) * (q_percent[i] / 100.0);
+            int64_t prev = (int64_t)std::floor(vi);
+            double g = vi - (double)prev;
+            if (prev < 0) { prev = 0; g = 0.0; }
+            int64_t next = prev + 1;
+            if (next > nv - 1) next = nv - 1;
+            gamma[i] = g;
+            ranks.push_back(prev);
+            ranks.push_back(next < 0 ? 0 : next);
+        }
+        return ranks;
+    };
+    std::vector<int64_t> ranks;
+    std::vector<double> values;
     int64_t nv = 0;
-    double lowest = 0.0;
-    rc = select_kth(d_x, n, 0, d_hist, d_nvalid, &lowest, &nv);    // also counts the non-NaN values
+    int rc = select_ranks(d_x, n, plan, ranks, values, &nv);
+    if (!rc && nv == 0) rc = fail("order statistic index out of range");
     for (int i = 0; i < nq && !rc; ++i) {
-        // NumPy: q = percent / 100 ; virtual index = (n - 1) * q ; linear interpolation between the neighbours
-        const double q = q_percent[i] / 100.0;
-        if (!(q >= 0.0 && q <= 1.0)) { rc = fail("mlmc_percentiles: percentiles must be in [0, 100]"); break; }
-        const double vi = (double)(nv - 1) * q;
-        int64_t prev = (int64_t)std::floor(vi);
-        double gamma = vi - (double)prev;
-        if (prev < 0) { prev = 0; gamma = 0.0; }
-        int64_t next = prev + 1;
-        if (next > nv - 1) next = nv - 1;
-        double a = lowest, b;
-        if (prev > 0) rc = select_kth(d_x, n, prev, d_hist, d_nvalid, &a, nullptr);
-        if (rc) break;
-        b = a;
-        if (next != prev) rc = select_kth(d_x, n, next, d_hist, d_nvalid, &b, nullptr);
-        if (rc) break;
+        const double a = values[2 * i], b = values[2 * i + 1];
         const double diff = b - a;
-        double r = a + diff * gamma;                      // numpy.lib._function_base_impl._lerp
-        if (gamma >= 0.5) r = b - diff * (1.0 - gamma);
+        double r = a + diff * gamma[i];                   // numpy.lib._function_base_impl._lerp
+        if (gamma[i] >= 0.5) r = b - diff * (1.0 - gamma[i]);
         out[i] = r;
     }
     if (n_valid) *n_valid = nv;
-    (void)hipFree(d_hist);
     if (own) (void)hipFree(d_x);
     return rc;
 }
