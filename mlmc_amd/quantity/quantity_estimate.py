@@ -138,6 +138,11 @@ class _DeviceChunkCache:
         self._bytes += nbytes
         return item
 
+    def drop(self, key):
+        item = self._items.pop(key, None)
+        if item is not None:
+            self._bytes -= item[2]
+
     def clear(self):
         self._items.clear()
         self._bytes = 0
@@ -238,19 +243,48 @@ def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache):
     return fine, coarse
 
 
+def _cache_ident(source, plan):
+    """Identity of a quantity's rows in the device cache: (storage, lowered program) for lowered trees -- equivalent
+    trees (rebuilt quantity objects, a second make_root_quantity over the same storage) share entries -- else the
+    quantity object itself."""
+    if plan is not None:
+        return (id(getattr(plan.leaf, "_storage", plan.leaf)), plan.signature)
+    return id(source)
+
+
+def _chunk_key(ident, chunk_spec, n_collected):
+    sl = chunk_spec.chunk_slice
+    return (ident, chunk_spec.level_id, chunk_spec.chunk_id, None if sl is None else (sl.start, sl.stop),
+            None if n_collected is None else n_collected[int(chunk_spec.level_id)])
+
+
+def _merge_level(pairs):
+    """The resident chunks of one level as one tensor pair (one device copy), or None when they are not all resident /
+    not all of one kind / too large to hold twice for a moment."""
+    import torch
+    pairs = [p for p in pairs if p is not None and p[0].shape[-1] > 0]
+    if len(pairs) < 2 or not all(isinstance(p[0], torch.Tensor) for p in pairs):
+        return None
+    if len({p[1] is None for p in pairs}) != 1:
+        return None
+    nbytes = sum(p[0].numel() * 8 * (1 if p[1] is None else 2) for p in pairs)
+    if 2 * nbytes > _DeviceChunkCache.budget():
+        return None
+    from .. import _lib
+    _lib.check(_lib.lib().mlmc_synchronize())                     # the chunks may still be being written by k_expr
+    fine = torch.cat([p[0] for p in pairs], dim=1).contiguous()
+    coarse = None if pairs[0][1] is None else torch.cat([p[1] for p in pairs], dim=1).contiguous()
+    torch.cuda.current_stream(fine.device).synchronize()          # the library reads them on its own stream
+    return fine, coarse
+
+
 def _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache):
     """Sample rows of `source` for one storage chunk, ready for the accumulators: (fine [M, n], coarse [M, n] | None) as
     torch CUDA tensors (resident: served from / added to the HBM cache) or, when the chunk does not fit the cache budget
     and the tree is evaluated on the host, as NumPy arrays that go through the staging buffer of the C ABI."""
-    sl = chunk_spec.chunk_slice
-    if plan is not None:
-        # equivalent trees (rebuilt quantity objects, a second make_root_quantity over the same storage) share entries
-        owner = getattr(plan.leaf, "_storage", plan.leaf)
-        ident = (id(owner), plan.signature)
-    else:
-        owner, ident = source, id(source)
-    key = (ident, chunk_spec.level_id, chunk_spec.chunk_id, None if sl is None else (sl.start, sl.stop),
-           None if n_collected is None else n_collected[int(chunk_spec.level_id)])
+    owner = getattr(plan.leaf, "_storage", plan.leaf) if plan is not None else source
+    ident = _cache_ident(source, plan)
+    key = _chunk_key(ident, chunk_spec, n_collected)
     item = _device_cache.get(key) if use_cache else None
     if item is not None:
         return item[0], item[1]
@@ -357,23 +391,63 @@ def estimate_mean(quantity, group=None, variance=True):
     except Exception:
         n_collected = None
         use_cache = False
-    for chunk_spec in storage_q.chunks():
-        pair = _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache)     # (fine [M, n], coarse | None)
-        if pair is not None and subsample_params is not None and pair[0].shape[-1] > 0:
-            pair = _subsample_on_device(pair, subsample_params[int(chunk_spec.level_id)])
-        if pair is None or pair[0].shape[-1] == 0:               # empty chunk / every sample deselected
-            if acc is None and pair is not None:
-                n_comp = pair[0].shape[0]
-                acc = _acc_pool.take(fn, n_levels, mode, n_comp, mean_only=not variance)
-            continue
-        fine, coarse = pair
+    # A level that arrives in several resident chunks (HDF5 files deliver levels that way) is concatenated into ONE tensor
+    # per level before it is pushed -- once; the level-wide entry replaces the chunk entries in the cache -- so every
+    # estimate, the first one included, is one push per level and gives bit-identical sums.
+    consolidate = use_cache and subsample_params is None
+    ident = _cache_ident(source, plan)
+    owner = getattr(plan.leaf, "_storage", plan.leaf) if plan is not None else source
+
+    def push_pair(level_id, pair):
+        nonlocal acc, n_comp
+        if pair is None:
+            return
         if acc is None:
-            n_comp = fine.shape[0]
-            assert n_comp * rows_per_comp == quantity_vec_size
+            n_comp = pair[0].shape[0]
+            if pair[0].shape[-1] > 0:
+                assert n_comp * rows_per_comp == quantity_vec_size
             acc = _acc_pool.take(fn, n_levels, mode, n_comp, mean_only=not variance)
+        if pair[0].shape[-1] == 0:                               # empty chunk / every sample deselected
+            return
+        fine, coarse = pair
         if n_comp == 1:
             fine, coarse = fine[0], (None if coarse is None else coarse[0])
-        acc.push(chunk_spec.level_id, fine, coarse)
+        acc.push(level_id, fine, coarse)
+
+    def flush_level(level_id, pairs, keys):
+        if not pairs:
+            return
+        merged = _merge_level(pairs) if (consolidate and len(pairs) > 1) else None
+        if merged is None:
+            for pair in pairs:
+                push_pair(level_id, pair)
+            return
+        _device_cache.put_tensors((ident, level_id, "level", n_collected[level_id]), merged[0], merged[1], owner=owner)
+        for key in keys:
+            _device_cache.drop(key)
+        push_pair(level_id, merged)
+
+    level_done = set()
+    if consolidate:
+        for level_id in sorted({int(l) for l in level_ids}):
+            item = _device_cache.get((ident, level_id, "level", n_collected[level_id]))
+            if item is not None:
+                level_done.add(level_id)
+                push_pair(level_id, (item[0], item[1]))
+    current, pairs, keys = None, [], []
+    for chunk_spec in storage_q.chunks():
+        level_id = int(chunk_spec.level_id)
+        if level_id in level_done:
+            continue
+        if level_id != current:
+            flush_level(current, pairs, keys)
+            current, pairs, keys = level_id, [], []
+        pair = _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache)     # (fine [M, n], coarse | None)
+        if pair is not None and subsample_params is not None and pair[0].shape[-1] > 0:
+            pair = _subsample_on_device(pair, subsample_params[level_id])
+        pairs.append(pair)
+        keys.append(_chunk_key(ident, chunk_spec, n_collected))
+    flush_level(current, pairs, keys)
     if acc is None:
         raise Exception("All samples were masked")
     n_samples, n_rm_samples, sums, sums_sq = acc.finalize(group=group)

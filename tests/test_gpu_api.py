@@ -351,7 +351,8 @@ def test_device_chunk_cache(hip):
     assert cache.uploads - u0 == n_chunks and cache.hits == h0
     m2, v2 = est.estimate_moments()
     cov, _ = est.estimate_covariance()
-    assert cache.uploads - u0 == n_chunks and cache.hits - h0 == 2 * n_chunks
+    # no further upload; the levels that came in several chunks are served as one consolidated tensor per level
+    assert cache.uploads - u0 == n_chunks and cache.hits - h0 == 2 * 3
     assert np.array_equal(m1, m2) and np.array_equal(v1, v2) and np.allclose(cov[:, 0], m1, atol=1e-12)
     # appended samples change n_collected -> the grown level is uploaded again, results follow the storage
     f, c = levels[2]
