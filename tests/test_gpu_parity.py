@@ -812,3 +812,35 @@ def test_estimate_in_one_call(hip):
             got = acc.estimate(chunks)
             assert all(np.array_equal(a, b) for a, b in zip(got, ref))
         acc.close()
+
+
+def test_many_levels_span_several_launches(hip):
+    """20 levels: more segments than one launch carries (16) -- the estimate is split over two launches; moments and
+    covariance against the oracle, device-resident and host pushes."""
+    import torch
+    from mlmc_amd import Legendre
+    from mlmc_amd.engine import LevelAccumulator
+    L = 20
+    steps = [0.5 * 0.8 ** l for l in range(L)]
+    N = [4000 - 150 * l for l in range(L)]
+    levels = level_arrays(N, steps, 1, 9)
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    dev = torch.device("cuda", 0)
+    for R, mode, rows in ((11, LevelAccumulator.MOMENTS, onp.moments_rows), (6, LevelAccumulator.COV, onp.covariance_rows)):
+        b = onp.Basis(onp.LEGENDRE, R, dom)
+        ref = onp.estimate_mean(to_chunks(levels), lambda x: rows(b, x))
+        for resident in (True, False):
+            acc = LevelAccumulator(Legendre(R, dom), L, mode)
+            keep = []
+            for l, (f, c) in enumerate(levels):
+                if resident:
+                    ft = torch.from_numpy(f[0]).to(dev)
+                    ct = None if c is None else torch.from_numpy(c[0]).to(dev)
+                    keep.append((ft, ct))
+                    torch.cuda.synchronize()
+                    acc.push(l, ft, ct)
+                else:
+                    acc.push(l, f[0], None if c is None else c[0])
+            n, n_rm, s, sp = acc.finalize()
+            acc.close()
+            _check_against(n, n_rm, s, sp, ref)
