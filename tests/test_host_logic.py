@@ -163,3 +163,25 @@ def test_moments_objects_host_side():
     assert tm2._base is fn and np.array_equal(tm2._base_matrix, np.ones((2, 3)) @ np.eye(3, 5))
     with pytest.raises(AssertionError):
         TransformedMoments(fn, np.eye(3, 4))
+
+
+def test_synth_device_storage_interface_without_gpu():
+    """Bookkeeping of SynthDeviceStorage (chunks, shards, costs, result format) needs no device."""
+    from mlmc_amd.sim.synth_device import SynthDeviceStorage, n_ops_estimate, result_format
+    st = SynthDeviceStorage([[0.5], [0.1], [0.02]], [1000, 500, 250], chunk_size=400)
+    assert st.get_n_levels() == 3 and st.get_level_ids() == [0, 1, 2] and st.get_n_collected() == [1000, 500, 250]
+    assert st.get_level_parameters() == [[0.5], [0.1], [0.02]]
+    chunks = list(st.chunks())
+    assert [(c.level_id, c.chunk_slice.start, c.chunk_slice.stop) for c in chunks] == \
+        [(0, 0, 400), (0, 400, 800), (0, 800, 1000), (1, 0, 400), (1, 400, 500), (2, 0, 250)]
+    assert [c.chunk_slice.stop for c in st.chunks(level_id=0, n_samples=450)] == [400, 450]
+    assert np.allclose(st.get_n_ops(), [n_ops_estimate(h) for h in (0.5, 0.1, 0.02)])
+    assert np.isclose(n_ops_estimate(0.1), 100 * np.log(10.0))                    # synth_simulation.py:133-134
+    fmt = result_format()
+    assert [q.name for q in fmt] == ["length", "width"] and fmt[0].shape == (2, 1) and fmt[0].times == [1, 2, 3]
+    # shards: contiguous slices of every level (engine.shard_bounds), together the whole level
+    parts = [SynthDeviceStorage([[0.5], [0.1]], [1001, 77], shard=(r, 4)) for r in range(4)]
+    assert [sum(p.get_n_collected()[l] for p in parts) for l in range(2)] == [1001, 77]
+    assert [p._first[0] for p in parts] == [0, 250, 500, 750]
+    with pytest.raises(NotImplementedError):
+        st.save_samples({}, {})
