@@ -142,7 +142,7 @@ int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64
 __device__ unsigned long long *g_prof;   // tools/dev/prof_moments.hip
 #endif
 constexpr int MAX_SEG = 16;
-constexpr int PRIO_SLICE_BITS = 15;   // 32768 cycles = 14 us at 2.4 GHz, a few trips of the sample loop
+constexpr int PRIO_SLICE_BITS = 16;   // 65536 cycles = 27 us at 2.4 GHz (A/B of 13..17 on one box: 16 and 17 best by ~1 %)
 struct Seg {
     const double *fine, *coarse;   // coarse == nullptr: level 0
     const uint8_t *mask;           // optional keep flags (quantities with M > 1 components)
