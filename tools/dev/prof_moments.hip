@@ -23,6 +23,7 @@ int main(int argc, char **argv) {
     bp.ref0 = -1; bp.ref1 = 1; bp.is_log = 0; bp.is_clip = 1;
     SegTable tab{};
     tab.nseg = 3;
+    tab.prio_mod = 2;
     tab.seg[0] = Seg{d[0], nullptr, nullptr, n, 0, nb0};
     tab.seg[1] = Seg{d[1], d[2], nullptr, n, nb0, nb1};
     tab.seg[2] = Seg{d[3], d[4], nullptr, n, nb0 + nb1, nb1};
