@@ -379,7 +379,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
     if ((threadIdx.x & 63) == 0) {   // per wave: start, loop end, block end (100 MHz ticks); shader cycles of the loop; XCC/CU id
         unsigned long long *p = g_prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 5;
         p[0] = prof_r0; p[1] = prof_r1; p[2] = __builtin_amdgcn_s_memrealtime(); p[3] = prof_c1 - prof_c0;
-        p[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        p[4] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_ID
+               ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);   // XCC_ID
     }
 #endif
 }

@@ -80,6 +80,33 @@ int main(int argc, char **argv) {
         if (hist[key]++ == 0) ++simds_used;
         max_per_simd = std::max(max_per_simd, hist[key]);
     }
+    {   // where do the early finishers live?  (loop end more than 12 % before the median)
+        std::vector<double> le;
+        for (size_t w = 0; w < (size_t)total * 4; ++w) le.push_back((p[w * 5 + 1] - t0) / 100.0);
+        std::vector<double> srt = le;
+        std::sort(srt.begin(), srt.end());
+        const double med = srt[srt.size() / 2];
+        int early_xcc[16] = {0}, all_xcc[16] = {0}, early_slot[16] = {0}, early_seg[3] = {0};
+        int early_se[8] = {0};
+        for (size_t w = 0; w < (size_t)total * 4; ++w) {
+            const unsigned hw = (unsigned)p[w * 5 + 4], xcc = (unsigned)(p[w * 5 + 4] >> 32) & 15;
+            all_xcc[xcc]++;
+            if (le[w] < 0.88 * med) {
+                early_xcc[xcc]++;
+                early_slot[hw & 15]++;
+                early_se[(hw >> 13) & 7]++;
+                const int blk = (int)(w / 4);
+                early_seg[blk < tab.seg[1].block0 ? 0 : (blk < tab.seg[2].block0 ? 1 : 2)]++;
+            }
+        }
+        printf("median loop end %.1f us; early waves per XCC:", med);
+        for (int i = 0; i < 8; ++i) printf(" %d/%d", early_xcc[i], all_xcc[i]);
+        printf("\n  early by wave slot:");
+        for (int i = 0; i < 4; ++i) printf(" [%d]=%d", i, early_slot[i]);
+        printf("  by SE:");
+        for (int i = 0; i < 8; ++i) printf(" %d", early_se[i]);
+        printf("  by segment: %d %d %d\n", early_seg[0], early_seg[1], early_seg[2]);
+    }
     int slot_hist[16] = {0};
     for (size_t w = 0; w < (size_t)total * 4; ++w) slot_hist[p[w * 5 + 4] & 15]++;
     printf("wave slots:");
