@@ -223,7 +223,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     constexpr int TA = 64 * BD;
     constexpr int N_EVAL = TA + NT;
     constexpr int NS = sym_n(W);
-    constexpr int NFULL = (MODE == 0 && PAIR) ? 2 : 0;     // G0, G1: full row W
+    constexpr int NFULL = (MODE == 0 && PAIR) ? 2 : ((MODE == 2 && PAIR) ? 1 : 0);     // G0 (and G1): full row W
     constexpr int NSYMM = (MODE == 0 && !PAIR) ? 2 : 1;    // symmetric matrices handled through the tile list
     const int lane = threadIdx.x & 63;
 
@@ -314,7 +314,11 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
                     accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[sym_i(W, t)], d[sym_j(W, t)], accs[0][t], 0, 0, 0);
                     accs[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[sym_i(W, t)], f2[sym_j(W, t)], accs[1][t], 0, 0, 0);
                 }
-            } else {                  // MODE 1: D^T D
+            } else if (MODE == 2 && PAIR) {   // covariance mean only: G0 = D^T S, row tile W
+#pragma unroll
+                for (int J = 0; J < 4; ++J)
+                    accf[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[W], sm[J], accf[0][J], 0, 0, 0);
+            } else {                  // MODE 1: D^T D;  MODE 2 at level 0: F^T F (d = f)
 #pragma unroll
                 for (int t = 0; t < NS; ++t)
                     accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[sym_i(W, t)], d[sym_j(W, t)], accs[0][t], 0, 0, 0);
@@ -338,8 +342,14 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
                 prow[1 * NT * NT + row * NT + col] = accf[1][J][r];
             }
     }
+    if (MODE == 2 && PAIR) {
 #pragma unroll
-    for (int t = 0; t < NS; ++t)
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) prow[(16 * W + r0 + 4 * r) * NT + 16 * J + c0] = accf[0][J][r];
+    }
+#pragma unroll
+    for (int t = 0; t < ((MODE == 2 && PAIR) ? 0 : NS); ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * sym_i(W, t) + r0 + 4 * r, col = 16 * sym_j(W, t) + c0;
@@ -422,7 +432,7 @@ template <int KIND, int T, int MODE, int BI, int BJ>
 static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, const double *d_f, const double *d_c,
                         const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
     hipStream_t st = rt().stream;
-    if constexpr (T == 4 && BI == BJ && MODE != 2) {   // diagonal 64 x 64 block: symmetric, wave-specialised kernel
+    if constexpr (T == 4 && BI == BJ) {   // diagonal 64 x 64 block: wave-specialised kernel (symmetric tiles used where they exist)
         if (pair)
             hipLaunchKernelGGL((k_cov_accum_t4<KIND, true, MODE, BI>), dim3(blocks), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
         else
