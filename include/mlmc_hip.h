@@ -200,14 +200,18 @@ typedef struct mlmc_expr mlmc_expr;
 int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_regs, int32_t n_in_rows, int32_t n_out_rows,
                      mlmc_expr **out);
 void mlmc_expr_destroy(mlmc_expr *e);
-/* Evaluate for n samples.  rows_in: host array of n_in_rows DEVICE pointers; each row is the storage layout of one
- * stored row of a chunk: interleaved (fine, coarse) pairs [n][2] when has_coarse, else [n] (level 0).
+/* Evaluate for n samples.  rows_in: host array of n_in_rows DEVICE pointers to the first fine value of each stored
+ * row; value (sample i, fine) = row[i * sample_stride], (sample i, coarse) = row[i * sample_stride + side_stride] (doubles).
+ * Two layouts occur: a row uploaded on its own -- interleaved (fine, coarse) pairs [n][2], strides (2, 1), level 0 [n],
+ * stride 1 -- and a row inside an uploaded storage block [n][2][M] (the layout of the reference's Memory storage and HDF5
+ * `collected_values`, sample_storage.py:169-184): pointer block + m, strides (2 M, M): fine / coarse are de-interleaved on
+ * the device, the host never reshuffles.
  * fine_out / coarse_out: device buffers of n_out_rows * n doubles (coarse_out ignored without has_coarse).  Without
  * MLMC_X_SELECT the result rows are [n_out_rows][n]; with it the selected samples are compacted in order and the rows
  * are [n_out_rows][*n_selected] contiguous.  n_selected (host) receives the surviving sample count; the call
  * synchronises only when the program selects. */
-int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coarse, int64_t n, double *fine_out,
-                   double *coarse_out, int64_t *n_selected);
+int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coarse, int64_t n, int64_t sample_stride,
+                   int64_t side_stride, double *fine_out, double *coarse_out, int64_t *n_selected);
 /* HIP-event time (ms), launches and algorithmic bytes (8 B per value of every referenced stored row and every result
  * row) of the evaluation kernel since create or the previous call; same contract as mlmc_accum_kernel_time. */
 int mlmc_expr_kernel_time(mlmc_expr *e, double *ms, int64_t *launches, int64_t *alg_bytes);

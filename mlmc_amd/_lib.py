@@ -71,7 +71,7 @@ SIGNATURES = {
     "mlmc_density_integrate": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, _vp, C.c_int64, C.c_int32, _vp]),
     "mlmc_expr_create": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "mlmc_expr_destroy": (None, [_vp]),
-    "mlmc_expr_eval": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, _vp, _vp, _ip]),
+    "mlmc_expr_eval": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _ip]),
     "mlmc_expr_kernel_time": (C.c_int, [_vp, _dp, _ip, _ip]),
     "mlmc_synth_generate": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                       C.c_int32, _vp, _vp]),

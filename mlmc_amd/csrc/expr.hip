@@ -164,7 +164,8 @@ struct RowTable {
 // memory-level parallelism.
 template <bool PAIR, int S, bool HEAVY>
 __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__restrict__ prog, int n_instr, RowTable tab,
-                                                    const double *const *__restrict__ rows, int64_t n, int n_regs,
+                                                    const double *const *__restrict__ rows, int64_t n, int64_t ss, int64_t cs,
+                                                    int n_regs,
                                                     double *__restrict__ out_f, double *__restrict__ out_c,
                                                     uint8_t *__restrict__ keep_out) {
     extern __shared__ double regs[];   // [n_regs][sides][S][X_THREADS]
@@ -186,10 +187,18 @@ __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__res
             const double *__restrict__ row = rows ? rows[ins.a] : tab.p[ins.a];
             if (PAIR) {
                 double2 v[S];
+                if (ss == 2 && cs == 1) {           // interleaved (fine, coarse) pairs: one 128-bit load per sample
 #pragma unroll
-                for (int k = 0; k < S; ++k) {       // S independent 128-bit loads in flight
-                    const int64_t i = i0 + (int64_t)k * X_THREADS;
-                    v[k] = i < n ? reinterpret_cast<const double2 *>(row)[i] : make_double2(0.0, 0.0);
+                    for (int k = 0; k < S; ++k) {   // S independent loads in flight
+                        const int64_t i = i0 + (int64_t)k * X_THREADS;
+                        v[k] = i < n ? reinterpret_cast<const double2 *>(row)[i] : make_double2(0.0, 0.0);
+                    }
+                } else {                            // a row of a stored [n][2][M] block: strides 2 M (sample), M (side)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) {
+                        const int64_t i = i0 + (int64_t)k * X_THREADS;
+                        v[k] = i < n ? make_double2(row[i * ss], row[i * ss + cs]) : make_double2(0.0, 0.0);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__res
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
                     const int64_t i = i0 + (int64_t)k * X_THREADS;
-                    v[k] = i < n ? row[i] : 0.0;
+                    v[k] = i < n ? row[i * ss] : 0.0;
                 }
 #pragma unroll
                 for (int k = 0; k < S; ++k) d[k * X_THREADS] = v[k];
@@ -390,12 +399,13 @@ void mlmc_expr_destroy(mlmc_expr *e) {
     delete e;
 }
 
-int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coarse, int64_t n, double *fine_out,
-                   double *coarse_out, int64_t *n_selected) {
+int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coarse, int64_t n, int64_t sample_stride,
+                   int64_t side_stride, double *fine_out, double *coarse_out, int64_t *n_selected) {
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!e || !rows_in || !fine_out) return fail("mlmc_expr_eval: null argument");
     if (has_coarse && !coarse_out) return fail("mlmc_expr_eval: coarse_out is NULL");
     if (n < 0 || n > ((int64_t)1 << 31)) return fail("mlmc_expr_eval: n out of range, split the chunk");
+    if (sample_stride < 1 || (has_coarse && side_stride < 1)) return fail("mlmc_expr_eval: strides must be positive");
     for (int r = 0; r < e->n_in; ++r)
         if (!rows_in[r]) return fail("mlmc_expr_eval: a stored row pointer is NULL");
     if (n_selected) *n_selected = n;
@@ -456,7 +466,7 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
         MLMC_HIP_CHECK(hipEventRecord(e->ev[e->ev_used], st));
     }
 #define MLMC_X_LAUNCH(P, SS, H)                                                                                            \
-    hipLaunchKernelGGL((k_expr<P, SS, H>), dim3(blocks), dim3(X_THREADS), lds, st, e->d_prog, n_instr, tab, d_rows, n, e->n_regs, \
+    hipLaunchKernelGGL((k_expr<P, SS, H>), dim3(blocks), dim3(X_THREADS), lds, st, e->d_prog, n_instr, tab, d_rows, n, sample_stride, side_stride, e->n_regs, \
                        tf, tc, keep)
 #define MLMC_X_LAUNCH_S(P, H)                                                                                              \
     do {                                                                                                                   \

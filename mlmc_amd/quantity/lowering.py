@@ -339,9 +339,10 @@ class DevicePlan:
             self._handle = h
         return self._handle
 
-    def evaluate(self, rows, has_coarse, n, sync=False):
-        """rows: device tensors of the stored rows in slot order ([n, 2] interleaved pairs, or [n] at level 0), complete
-        in memory (the caller has synchronised the stream that produced them).
+    def evaluate(self, rows, has_coarse, n, sync=False, sample_stride=None, side_stride=1):
+        """rows: device tensors of the stored rows in slot order ([n, 2] interleaved pairs, or [n] at level 0; or views
+        into an uploaded storage block [n, 2, M] starting at the row's first value, with sample_stride = 2 M and
+        side_stride = M), complete in memory (the caller has synchronised the stream that produced them).
         -> fine [n_out, n'], coarse [n_out, n'] | None as torch CUDA tensors (n' <= n when the quantity selects).
         The kernel runs on the library's stream: the library's own consumers (accumulators) are ordered behind it;
         pass sync=True before reading the tensors with torch."""
@@ -351,7 +352,10 @@ class DevicePlan:
         coarse = torch.empty(self.n_out * n, dtype=torch.float64, device=dev) if has_coarse else None
         table = (C.c_void_p * len(rows))(*[r.data_ptr() for r in rows])
         n_sel = C.c_int64(n)
-        _lib.check(_lib.lib().mlmc_expr_eval(self.handle(), table, 1 if has_coarse else 0, int(n), fine.data_ptr(),
+        if sample_stride is None:                      # rows uploaded on their own: [n, 2] pairs or [n, 1]
+            sample_stride = 2 if has_coarse else 1
+        _lib.check(_lib.lib().mlmc_expr_eval(self.handle(), table, 1 if has_coarse else 0, int(n), int(sample_stride),
+                                             int(side_stride), fine.data_ptr(),
                                              None if coarse is None else coarse.data_ptr(), C.byref(n_sel)))
         if sync:
             _lib.check(_lib.lib().mlmc_synchronize())

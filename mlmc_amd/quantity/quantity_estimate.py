@@ -231,8 +231,50 @@ def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache):
     return t
 
 
+def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache):
+    """The whole stored chunk as ONE device buffer in the storage's own [n][2][M] layout (reference Memory storage and
+    HDF5 `collected_values`, sample_storage.py:169-184), when the host view allows it: -> (flat device tensor,
+    sample stride, side stride, n, width) or None.  One contiguous PCIe copy replaces one strided host gather per
+    stored row (a row of an [n][2][M] array touches a separate cache line per value once M >= 8); k_expr de-interleaves
+    while loading (strided LOAD).  Taken when the tree reads at least 1/8 of the stored rows."""
+    import torch
+    storage = getattr(plan.leaf, "_storage", None)
+    if hasattr(storage, "device_row") or os.environ.get("MLMC_HIP_BLOCK_UPLOAD", "1") == "0":
+        return None
+    owner = storage if storage is not None else plan.leaf
+    key = ("block", id(owner)) + chunk_key
+    item = _device_cache.get(key) if use_cache else None
+    raw = plan.leaf.samples(chunk_spec)                           # [M_stored, n, 2|1] view of the storage
+    m_total, n, width = raw.shape
+    if n == 0 or m_total < 2 or raw.dtype != np.float64 or len(plan.in_rows) * 8 < m_total:
+        return None
+    sm, sn, sw = (st // 8 for st in raw.strides)
+    if sm != 1 or sn < m_total or (width == 2 and sw < m_total) or any(st % 8 for st in raw.strides):
+        return None                                              # not an [n][sides][M] record array
+    span = (n - 1) * sn + (width - 1) * sw + m_total              # doubles between the first and the last value
+    if span > 3 * raw.size or span * 8 > _DeviceChunkCache.budget() // 4:
+        return None
+    if item is None:
+        flat = np.lib.stride_tricks.as_strided(raw, shape=(span,), strides=(8,))
+        dev = torch.device("cuda", _lib_device())
+        t = torch.from_numpy(flat).to(dev)
+        torch.cuda.current_stream(dev).synchronize()             # the library reads it on its own stream
+        _device_cache.uploads += 1
+        if use_cache:
+            _device_cache.put_tensors(key, t, None, owner=owner)
+    else:
+        t = item[0]
+    return t, sn, sw, n, width
+
+
 def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache):
     """Result rows of a lowered quantity for one chunk: fine [M, n'], coarse [M, n'] | None (torch CUDA tensors)."""
+    blk = _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache)
+    if blk is not None:
+        t, sn, sw, n, width = blk
+        fine, coarse, _ = plan.evaluate([t[r:] for r in plan.in_rows], has_coarse=(width == 2), n=n, sample_stride=sn,
+                                        side_stride=sw)
+        return fine, coarse
     rows = [_stored_row_on_device(plan, chunk_spec, chunk_key, r, use_cache) for r in plan.in_rows]
     n, width = rows[0].shape
     if n == 0:

@@ -529,6 +529,61 @@ def test_device_tree_shares_stored_rows_between_quantities(hip):
     qe.device_cache_clear()
 
 
+def test_device_tree_block_upload_matches_row_upload(hip):
+    """Stored chunks uploaded whole in the storage's [n][2][M] layout and de-interleaved by k_expr's strided LOAD give
+    bit-identical rows to per-row uploads (interleaved pairs), for every zoo expression, every chunk, level 0 included
+    (there the host view [n][1][M] skips the unused coarse half)."""
+    import torch
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from tests.test_lowering import _spec, expression_zoo, make_storage
+    st = make_storage((1300, 777, 258), chunk_size=500)
+    root = make_root_quantity(st, _spec())
+    dev = torch.device("cuda", 0)
+    for name, q in expression_zoo(root).items():
+        plan = lowering.lower(q)
+        for chunk in st.chunks():
+            stored = st.sample_pairs_level(chunk)                    # [M, n, 2|1]
+            m_total, n, width = stored.shape
+            rows = [torch.from_numpy(np.ascontiguousarray(stored[r])).to(dev) for r in plan.in_rows]
+            block = torch.from_numpy(np.ascontiguousarray(stored.transpose(1, 2, 0))).to(dev).view(-1)    # [n][width][M]
+            torch.cuda.synchronize()
+            f0, c0, _ = plan.evaluate(rows, has_coarse=(width == 2), n=n, sync=True)
+            f1, c1, _ = plan.evaluate([block[r:] for r in plan.in_rows], has_coarse=(width == 2), n=n, sync=True,
+                                       sample_stride=width * m_total, side_stride=m_total)
+            assert f0.shape == f1.shape, name
+            assert np.array_equal(f0.cpu().numpy(), f1.cpu().numpy(), equal_nan=True), (name, chunk.level_id)
+            if width == 2:
+                assert np.array_equal(c0.cpu().numpy(), c1.cpu().numpy(), equal_nan=True), (name, chunk.level_id)
+
+
+def test_device_tree_block_upload_in_estimates(hip, monkeypatch):
+    """estimate_mean over trees that read many stored rows takes the block upload (one copy per chunk); results equal the
+    per-row path bit for bit and the number of uploads drops from rows x chunks to chunks."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from tests.test_lowering import _spec, make_storage
+    st = make_storage((2600, 1500, 700), chunk_size=1000)
+    root = make_root_quantity(st, _spec())
+    n_chunks = len(list(st.chunks()))
+    fn = Legendre(7, (-1.5, 6.0))
+    q = root['length'].time_interpolation(1.5)['20'] * np.array([1.0, 0.5]) + root['width'][1]['30']   # reads 6 of 24 rows
+    res, uploads = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MLMC_HIP_BLOCK_UPLOAD", mode)
+        qe.device_cache_clear()
+        u0 = qe._device_cache.uploads
+        res[mode] = (qe.estimate_mean(qe.moments(q, fn)), qe.estimate_mean(root))
+        uploads[mode] = qe._device_cache.uploads - u0
+    assert uploads["1"] == n_chunks and uploads["0"] == 24 * n_chunks, (uploads, n_chunks)
+    for a, b in zip(res["1"], res["0"]):
+        assert a.n_samples.tolist() == b.n_samples.tolist()
+        assert np.array_equal(a.l_means, b.l_means) and np.array_equal(a.l_vars, b.l_vars)
+        assert np.array_equal(a.mean, b.mean) and np.array_equal(a.var, b.var)
+    qe.device_cache_clear()
+
+
 def test_device_subsample_gather(hip):
     """mlmc_subsample_gather: every output column is a column of the input (same index for all rows and for fine and
     coarse), the draw is reproducible from the seed, indices are uniform; and the estimate over a sub-sampled quantity
