@@ -5,5 +5,6 @@ mlmc.estimator, mlmc.tool.simple_distribution / distribution): same names and ca
 hand-written HIP kernels (libmlmc_hip.so, C ABI in include/mlmc_hip.h).  There is no CPU fallback.
 """
 from .moments import Moments, Monomial, Fourier, Legendre, Spline, TransformedMoments  # noqa: F401
+from .sampler import DeviceSampler  # noqa: F401
 
 __version__ = "0.1.0"

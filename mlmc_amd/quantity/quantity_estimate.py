@@ -143,6 +143,10 @@ class _DeviceChunkCache:
         if item is not None:
             self._bytes -= item[2]
 
+    def drop_owner(self, owner):
+        for key in [k for k, item in self._items.items() if item[3] is owner]:
+            self.drop(key)
+
     def clear(self):
         self._items.clear()
         self._bytes = 0
@@ -160,6 +164,11 @@ _device_cache = _DeviceChunkCache()
 def device_cache_clear():
     """Drop the HBM-resident sample chunks (call after modifying stored samples in place)."""
     _device_cache.clear()
+
+
+def device_cache_drop_owner(storage):
+    """Drop the resident chunks that came from one storage (it changed: grew, was refilled)."""
+    _device_cache.drop_owner(storage)
 
 
 def _split_fine_coarse(chunk, level_id):

@@ -63,15 +63,30 @@ class SynthDeviceStorage(SampleStorage):
         loc, scale: the distribution scipy.stats.norm(loc, scale) of SynthSimulation's config;
         shard: (rank, world_size) -- this process owns the contiguous slice engine.shard_bounds of every level
         (multi-GPU estimates: one process per GPU, the level sums are all-reduced by estimate_mean)."""
-        from ..engine import shard_bounds
         self._loc, self._scale = float(loc), float(scale)
         self._steps = [float(np.ravel(s)[0]) for s in level_steps]
-        bounds = [shard_bounds(int(v), *shard) if shard is not None else (0, int(v)) for v in n_samples]
-        self._first = [lo for lo, _ in bounds]             # sample index of the first owned sample of every level
-        self._n = [hi - lo for lo, hi in bounds]
+        self._shard = shard
+        self._set_counts(n_samples)
         assert len(self._steps) == len(self._n)
         self._chunk_size = chunk_size
         self._n_ops = [n_ops_estimate(h, complexity) for h in self._steps]
+
+    def _set_counts(self, n_samples):
+        from ..engine import shard_bounds
+        bounds = [shard_bounds(int(v), *self._shard) if self._shard is not None else (0, int(v)) for v in n_samples]
+        self._first = [lo for lo, _ in bounds]             # sample index of the first owned sample of every level
+        self._n = [hi - lo for lo, hi in bounds]
+
+    def set_n_samples(self, n_samples):
+        """Grow the levels to n_samples collected samples (job-wide counts; a shard re-derives its slice): the samples
+        are a function of (level, index), so new ones only extend every level's sequence (sampler.DeviceSampler).
+        Rows of the former extent that estimates left in the HBM cache are released."""
+        assert len(n_samples) == len(self._steps)
+        old = (list(self._first), list(self._n))
+        self._set_counts(n_samples)
+        if old != (self._first, self._n):
+            from ..quantity import quantity_estimate
+            quantity_estimate.device_cache_drop_owner(self)
 
     # ---- the part of the interface the estimators use ---------------------------------------------------------
     def get_level_ids(self):

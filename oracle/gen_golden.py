@@ -450,10 +450,91 @@ def g8_quantity_tree():
     print("G8", len(out) - 2, "chunks of", len(trees), "trees")
 
 
+def g9_sampler_loop():
+    """The reference's adaptive sampling loop (test/test_run.py:60-105): Sampler + OneProcessPool + SynthSimulation +
+    Memory, `estimate_diff_vars_regression` -> `estimate_n_samples_for_target_variance` -> `process_adding_samples`
+    until the estimate is met.  Recorded per round: the variances, n_estimated, the scheduled counts after the call and
+    the returned flag; at the end the moments.  Harness-side accommodations: Memory._save_successful is fed through an
+    object array (np.array of ragged tuples raises on NumPy >= 1.24) and the cost per sample is
+    SynthSimulation.n_ops_estimate(step) instead of the pool's measured wall time (not reproducible)."""
+    ruamel = types.ModuleType("ruamel")
+    ruamel.yaml = types.ModuleType("ruamel.yaml")
+    sys.modules.setdefault("ruamel", ruamel)
+    sys.modules.setdefault("ruamel.yaml", ruamel.yaml)
+    import scipy.stats as stats
+    import mlmc.moments as mm
+    import mlmc.quantity.quantity as q
+    import mlmc.estimator as est
+    from mlmc.sample_storage import Memory
+    from mlmc.sampler import Sampler
+    from mlmc.sampling_pool import OneProcessPool
+    from mlmc.sim.synth_simulation import SynthSimulation
+
+    class HarnessMemory(Memory):
+        def _save_successful(self, samples):
+            boxed = {}
+            for level_id, res in samples.items():
+                arr = np.empty((len(res), 2), dtype=object)
+                for i, (sid, pair) in enumerate(res):
+                    arr[i, 0] = sid
+                    arr[i, 1] = pair
+                boxed[level_id] = _Rows(arr)
+            super()._save_successful(boxed)
+
+    class _Rows:                                   # np.array(res) of the reference returns the object array as is
+        def __init__(self, arr):
+            self.arr = arr
+
+        def __array__(self, dtype=None, copy=None):
+            return self.arr
+
+        def __len__(self):
+            return len(self.arr)
+
+    cases = []
+    for name, step_range, n0, target_var, n_moments, loc, scale in (
+            ("two_levels_test_run", [[0.1], [0.001]], [10, 10], 1e-3, 5, 0.0, 1.0),
+            ("three_levels", [[0.3], [0.03], [0.003]], [200, 50, 20], 2e-5, 8, 0.0, 1.0),
+            ("five_levels_shifted", [[0.5], [0.19], [0.07], [0.027], [0.01]], [300, 10], 2e-5, 6, 1.0, 2.0)):
+        np.random.seed(1234)
+        distr = stats.norm(loc=loc, scale=scale)
+        sim = SynthSimulation(dict(distr=distr, complexity=2, nan_fraction=0))
+        st = HarnessMemory()
+        sampler = Sampler(sample_storage=st, sampling_pool=OneProcessPool(), sim_factory=sim, level_parameters=step_range)
+        st.get_n_ops = lambda sr=step_range, sim=sim: [sim.n_ops_estimate(s[0]) for s in sr]
+        true_domain = distr.ppf([0.0001, 0.9999])
+        fn = mm.Legendre(n_moments, true_domain)
+        sampler.set_initial_n_samples(n0)
+        sampler.schedule_samples()
+        sampler.ask_sampling_pool_for_samples()
+        root = q.make_root_quantity(st, q_specs=sim.result_format())
+        value = root['length'][1]['10'][0]
+        e = est.Estimate(value, st, fn)
+        rounds = []
+        initial = [int(v) for v in sampler._n_scheduled_samples]
+        while True:
+            variances, n_ops = e.estimate_diff_vars_regression(sampler._n_scheduled_samples)
+            n_est = est.estimate_n_samples_for_target_variance(target_var, variances, n_ops, n_levels=sampler.n_levels)
+            done = sampler.process_adding_samples(n_est, 0, 0.1)
+            rounds.append(dict(variances=np.asarray(variances).tolist(), n_ops=list(map(float, n_ops)),
+                               n_estimated=[int(v) for v in n_est], n_scheduled=[int(v) for v in sampler._n_scheduled_samples],
+                               n_finished=[int(v) for v in sampler.n_finished_samples], done=bool(done)))
+            if done:
+                break
+        means, vars_ = e.estimate_moments(fn)
+        cases.append(dict(name=name, level_parameters=step_range, initial=n0, initial_scheduled=initial, target_var=target_var,
+                          n_moments=n_moments, loc=loc, scale=scale, domain=list(map(float, true_domain)), rounds=rounds,
+                          means=np.asarray(means).tolist(), vars=np.asarray(vars_).tolist(),
+                          n_collected=[int(v) for v in st.get_n_collected()]))
+        print("G9", name, len(rounds), "rounds ->", cases[-1]["n_collected"])
+    with open(os.path.join(OUT, "G9_sampler_loop.json"), "w") as f:
+        json.dump(dict(cases=cases), f)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     _install_shims()
-    which = sys.argv[1:] or ["g1", "g2", "g5", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g5", "g7", "g8", "g9"]
     if "g1" in which:
         g1_basis()
     if "g2" in which:
@@ -464,3 +545,5 @@ if __name__ == "__main__":
         g7_chain()
     if "g8" in which:
         g8_quantity_tree()
+    if "g9" in which:
+        g9_sampler_loop()

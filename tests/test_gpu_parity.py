@@ -844,3 +844,42 @@ def test_many_levels_span_several_launches(hip):
             n, n_rm, s, sp = acc.finalize()
             acc.close()
             _check_against(n, n_rm, s, sp, ref)
+
+
+def test_adaptive_sampling_loop_matches_reference_trajectory(hip):
+    """The loop of the reference's test/test_run.py:93-105 with every part on the device: samples generated in HBM
+    (SynthDeviceStorage), level variances + regression from the device estimator, DeviceSampler scheduling.  Against the
+    reference's own run of that loop (G9): per round the variances (1e-10), n_estimated and the scheduled / collected
+    counts (exact), at the end the moments."""
+    import json
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate, estimate_n_samples_for_target_variance
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.sampler import DeviceSampler
+    from mlmc_amd.sim.synth_device import SynthDeviceStorage, result_format
+    with open(os.path.join(os.path.dirname(__file__), "golden", "G9_sampler_loop.json")) as f:
+        cases = json.load(f)["cases"]
+    for case in cases:
+        steps = case["level_parameters"]
+        st = SynthDeviceStorage(steps, [0] * len(steps), loc=case["loc"], scale=case["scale"])
+        sampler = DeviceSampler(st, level_parameters=steps)
+        fn = Legendre(case["n_moments"], tuple(case["domain"]))
+        sampler.set_initial_n_samples(case["initial"])
+        sampler.schedule_samples()
+        sampler.ask_sampling_pool_for_samples()
+        value = make_root_quantity(st, result_format())['length'][1]['10'][0]
+        est = Estimate(value, st, fn)
+        for i, rnd in enumerate(case["rounds"]):
+            variances, n_ops = est.estimate_diff_vars_regression(sampler._n_scheduled_samples)
+            want = np.array(rnd["variances"])
+            assert np.allclose(variances, want, rtol=1e-9, atol=1e-10 * np.max(np.abs(want))), (case["name"], i)
+            assert np.allclose(n_ops, rnd["n_ops"], rtol=1e-14)
+            n_est = estimate_n_samples_for_target_variance(case["target_var"], variances, n_ops, n_levels=sampler.n_levels)
+            assert [int(v) for v in n_est] == rnd["n_estimated"], (case["name"], i)
+            done = sampler.process_adding_samples(n_est, 0, 0.1)
+            assert [int(v) for v in sampler.l_scheduled_samples()] == rnd["n_scheduled"]
+            assert [int(v) for v in sampler.n_finished_samples] == rnd["n_finished"]
+            assert done == rnd["done"]
+        assert done
+        means, vars_ = est.estimate_moments(fn)
+        assert np.allclose(means, case["means"], rtol=0, atol=1e-10) and np.allclose(vars_, case["vars"], rtol=1e-9, atol=1e-16)

@@ -185,3 +185,37 @@ def test_synth_device_storage_interface_without_gpu():
     assert [p._first[0] for p in parts] == [0, 250, 500, 750]
     with pytest.raises(NotImplementedError):
         st.save_samples({}, {})
+
+
+def test_device_sampler_follows_the_reference_scheduling():
+    """DeviceSampler bookkeeping (no GPU: samples are generated only when read) replays the reference's adaptive loop
+    (Sampler + OneProcessPool, tests/golden/G9_sampler_loop.json from oracle/gen_golden.py g9): fed the recorded
+    n_estimated of every round it reproduces scheduled counts, the counts that reached the storage, and the flag."""
+    import json
+    import os
+    from mlmc_amd.sampler import DeviceSampler
+    from mlmc_amd.sim.synth_device import SynthDeviceStorage
+    with open(os.path.join(os.path.dirname(__file__), "golden", "G9_sampler_loop.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == 3
+    for case in cases:
+        steps = case["level_parameters"]
+        st = SynthDeviceStorage(steps, [0] * len(steps), loc=case["loc"], scale=case["scale"])
+        sampler = DeviceSampler(st, level_parameters=steps)
+        sampler.set_initial_n_samples(case["initial"])
+        sampler.schedule_samples()
+        assert sampler.ask_sampling_pool_for_samples() == 0
+        assert [int(v) for v in sampler.l_scheduled_samples()] == case["initial_scheduled"]
+        assert st.get_n_collected() == case["initial_scheduled"]
+        for rnd in case["rounds"]:
+            done = sampler.process_adding_samples(np.array(rnd["n_estimated"]), 0, 0.1)
+            assert [int(v) for v in sampler.l_scheduled_samples()] == rnd["n_scheduled"], case["name"]
+            assert [int(v) for v in sampler.n_finished_samples] == rnd["n_finished"], case["name"]
+            assert done == rnd["done"]
+        assert st.get_n_collected() == case["n_collected"]
+    # a level never shrinks; timeout <= 0 means "do not wait"
+    sampler.set_level_target_n_samples([1] * sampler.n_levels)
+    sampler.schedule_samples()
+    assert [int(v) for v in sampler.l_scheduled_samples()] == cases[-1]["rounds"][-1]["n_scheduled"]
+    assert sampler.ask_sampling_pool_for_samples(timeout=0) == 1
+    assert sampler.sample_range(1000, 10).tolist() == [1000, 316, 100, 32, 10]
