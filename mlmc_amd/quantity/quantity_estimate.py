@@ -245,7 +245,9 @@ def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache):
     HDF5 `collected_values`, sample_storage.py:169-184), when the host view allows it: -> (flat device tensor,
     sample stride, side stride, n, width) or None.  One contiguous PCIe copy replaces one strided host gather per
     stored row (a row of an [n][2][M] array touches a separate cache line per value once M >= 8); k_expr de-interleaves
-    while loading (strided LOAD).  Taken when the tree reads at least 1/8 of the stored rows."""
+    while loading (strided LOAD).  Taken when the tree reads at least 1/8 of the stored rows -- and for M = 1 at level 0,
+    where the storage keeps an unused coarse column ([n][2], the fine values at stride 2): copying 2x the bytes at link
+    speed beats a strided host gather of half of them (2.8 ms vs 8 ms + 1.4 ms for 10^7 samples)."""
     import torch
     storage = getattr(plan.leaf, "_storage", None)
     if hasattr(storage, "device_row") or os.environ.get("MLMC_HIP_BLOCK_UPLOAD", "1") == "0":
@@ -255,10 +257,17 @@ def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache):
     item = _device_cache.get(key) if use_cache else None
     raw = plan.leaf.samples(chunk_spec)                           # [M_stored, n, 2|1] view of the storage
     m_total, n, width = raw.shape
-    if n == 0 or m_total < 2 or raw.dtype != np.float64 or len(plan.in_rows) * 8 < m_total:
+    if n == 0 or raw.dtype != np.float64 or any(st % 8 for st in raw.strides):
         return None
     sm, sn, sw = (st // 8 for st in raw.strides)
-    if sm != 1 or sn < m_total or (width == 2 and sw < m_total) or any(st % 8 for st in raw.strides):
+    if m_total == 1:
+        sm = 1                                                   # the stride of a length-1 axis carries no meaning
+    if width == 1:
+        sw = 0
+    rows_are_ready = (sn == width and (width == 1 or sw == 1))   # raw[m] already is an [n][2] / [n] row: plain row upload
+    if rows_are_ready or (m_total > 1 and len(plan.in_rows) * 8 < m_total):
+        return None
+    if sm != 1 or sn < m_total * width or (width == 2 and sw < m_total):
         return None                                              # not an [n][sides][M] record array
     span = (n - 1) * sn + (width - 1) * sw + m_total              # doubles between the first and the last value
     if span > 3 * raw.size or span * 8 > _DeviceChunkCache.budget() // 4:
@@ -282,7 +291,7 @@ def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache):
     if blk is not None:
         t, sn, sw, n, width = blk
         fine, coarse, _ = plan.evaluate([t[r:] for r in plan.in_rows], has_coarse=(width == 2), n=n, sample_stride=sn,
-                                        side_stride=sw)
+                                        side_stride=max(sw, 1))
         return fine, coarse
     rows = [_stored_row_on_device(plan, chunk_spec, chunk_key, r, use_cache) for r in plan.in_rows]
     n, width = rows[0].shape
