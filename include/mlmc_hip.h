@@ -189,7 +189,14 @@ enum {
 /* flags or-ed into `op` of an arithmetic (ADD..FMOD) or comparison instruction: the operand is `imm`, not a register */
 #define MLMC_X_IMM_A 0x4000
 #define MLMC_X_IMM_B 0x8000
-#define MLMC_X_OP_MASK 0x3fff
+/* chaining: the result of the latest value-producing instruction (everything but STORE / SELECT) also stays in VGPRs.
+ * A_PREV / B_PREV: the operand is that result (the register index is ignored); NO_WB on a producing instruction: the
+ * result is read only through such chained operands and is not written to a register (`dst` is ignored).  Optional --
+ * a program without these flags computes the same rows, with every value passing through the LDS register file. */
+#define MLMC_X_A_PREV 0x2000
+#define MLMC_X_B_PREV 0x1000
+#define MLMC_X_NO_WB 0x0800
+#define MLMC_X_OP_MASK 0x07ff
 typedef struct {
     uint16_t op, dst, a, b;   /* registers < n_regs; LOAD: a = input row; STORE: b = output row */
     double imm;               /* CONST value, or the immediate operand */

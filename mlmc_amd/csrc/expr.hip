@@ -67,15 +67,30 @@ __device__ __forceinline__ double np_minimum(double a, double b) { return (a <= 
 __device__ __forceinline__ double np_sign(double a) { return a != a ? a : (a > 0.0 ? 1.0 : (a < 0.0 ? -1.0 : 0.0)); }
 
 // Register file in LDS: [reg][side][slot][thread]; a thread works on S samples (slots) per instruction so that the
-// decode of an instruction and the latency of its loads are shared by S samples.
-template <bool PAIR, int S, bool HEAVY>
-__device__ __forceinline__ void binary(int op, double *d, const double *x, const double *y, bool imm_a, bool imm_b,
-                                       double imm) {   // d may alias x or y; an immediate operand replaces a register read
-    constexpr int V = (PAIR ? 2 : 1) * S;
-    double r[V];
+// decode of an instruction and the latency of its loads are shared by S samples.  The result of the latest value-
+// producing instruction also stays in VGPRs (`prev`): an operand flagged MLMC_X_A_PREV / MLMC_X_B_PREV is taken from
+// there, and a result that is only ever read that way is not written to LDS at all (MLMC_X_NO_WB) -- expression chains
+// then run in registers and LDS carries only the values that outlive their successor.
+template <int V>
+__device__ __forceinline__ void fetch(double (&o)[V], bool is_imm, bool is_prev, double imm, const double (&prev)[V],
+                                      const double *x) {
+    if (is_imm) {
+#pragma unroll
+        for (int s = 0; s < V; ++s) o[s] = imm;
+    } else if (is_prev) {
+#pragma unroll
+        for (int s = 0; s < V; ++s) o[s] = prev[s];
+    } else {
+#pragma unroll
+        for (int s = 0; s < V; ++s) o[s] = x[s * X_THREADS];
+    }
+}
+
+template <int V, bool HEAVY>
+__device__ __forceinline__ void binary(int op, double (&r)[V], const double (&av)[V], const double (&bv)[V]) {
 #pragma unroll
     for (int s = 0; s < V; ++s) {
-        const double a = imm_a ? imm : x[s * X_THREADS], b = imm_b ? imm : y[s * X_THREADS];
+        const double a = av[s], b = bv[s];
         switch (op) {
             case MLMC_X_ADD: r[s] = a + b; break;
             case MLMC_X_SUB: r[s] = a - b; break;
@@ -95,17 +110,13 @@ __device__ __forceinline__ void binary(int op, double *d, const double *x, const
             default: r[s] = ((a != 0.0) != (b != 0.0)) ? 1.0 : 0.0; break;   // XOR
         }
     }
-#pragma unroll
-    for (int s = 0; s < V; ++s) d[s * X_THREADS] = r[s];
 }
 
-template <bool PAIR, int S, bool HEAVY>
-__device__ __forceinline__ void unary(int op, double *d, const double *x) {
-    constexpr int V = (PAIR ? 2 : 1) * S;
-    double r[V];
+template <int V, bool HEAVY>
+__device__ __forceinline__ void unary(int op, double (&r)[V], const double (&av)[V]) {
 #pragma unroll
     for (int s = 0; s < V; ++s) {
-        const double a = x[s * X_THREADS];
+        const double a = av[s];
         switch (op) {
             case MLMC_X_NEG: r[s] = -a; break;
             case MLMC_X_ABS: r[s] = fabs(a); break;
@@ -137,8 +148,6 @@ __device__ __forceinline__ void unary(int op, double *d, const double *x) {
             default: r[s] = (a == 0.0) ? 1.0 : 0.0; break;   // NOT
         }
     }
-#pragma unroll
-    for (int s = 0; s < V; ++s) d[s * X_THREADS] = r[s];
 }
 
 __device__ __forceinline__ bool compare(int op, double a, double b) {
@@ -170,12 +179,16 @@ __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__res
                                                     uint8_t *__restrict__ keep_out) {
     extern __shared__ double regs[];   // [n_regs][sides][S][X_THREADS]
     constexpr int SIDES = PAIR ? 2 : 1;
-    constexpr int REG_STRIDE = SIDES * S * X_THREADS;
+    constexpr int V = SIDES * S;       // values per thread and instruction: index side * S + slot
+    constexpr int REG_STRIDE = V * X_THREADS;
     const int64_t i0 = (int64_t)blockIdx.x * (S * X_THREADS) + threadIdx.x;
     double *const mine = regs + threadIdx.x;
     bool keep[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) keep[k] = true;
+    double prev[V];                    // result of the latest value-producing instruction
+#pragma unroll
+    for (int s = 0; s < V; ++s) prev[s] = 0.0;
     for (int pc = 0; pc < n_instr; ++pc) {
         const mlmc_expr_instr ins = prog[pc];
         double *const d = mine + (size_t)ins.dst * REG_STRIDE;
@@ -183,6 +196,29 @@ __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__res
         const double *const y = mine + (size_t)ins.b * REG_STRIDE;
         const int op = ins.op & MLMC_X_OP_MASK;
         const bool imm_a = (ins.op & MLMC_X_IMM_A) != 0, imm_b = (ins.op & MLMC_X_IMM_B) != 0;
+        const bool prev_a = (ins.op & MLMC_X_A_PREV) != 0, prev_b = (ins.op & MLMC_X_B_PREV) != 0;
+        const bool write_back = (ins.op & MLMC_X_NO_WB) == 0;
+        if (op == MLMC_X_STORE) {
+            double v[V];
+            fetch<V>(v, false, prev_a, 0.0, prev, x);
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const int64_t i = i0 + (int64_t)k * X_THREADS;
+                if (i < n) {
+                    out_f[(int64_t)ins.b * n + i] = v[k];
+                    if (PAIR) out_c[(int64_t)ins.b * n + i] = v[S + k];
+                }
+            }
+            continue;
+        }
+        if (op == MLMC_X_SELECT) {
+            double v[V];
+            fetch<V>(v, false, prev_a, 0.0, prev, x);
+#pragma unroll
+            for (int k = 0; k < S; ++k) keep[k] = keep[k] && (v[k] != 0.0);
+            continue;
+        }
+        // value-producing instructions: the result goes to `prev` and, unless flagged, to its LDS register
         if (op == MLMC_X_LOAD) {
             const double *__restrict__ row = rows ? rows[ins.a] : tab.p[ins.a];
             if (PAIR) {
@@ -202,51 +238,43 @@ __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__res
                 }
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
-                    d[k * X_THREADS] = v[k].x;
-                    d[(S + k) * X_THREADS] = v[k].y;
+                    prev[k] = v[k].x;
+                    prev[(V - S) + k] = v[k].y;
                 }
             } else {
-                double v[S];
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
                     const int64_t i = i0 + (int64_t)k * X_THREADS;
-                    v[k] = i < n ? row[i * ss] : 0.0;
-                }
-#pragma unroll
-                for (int k = 0; k < S; ++k) d[k * X_THREADS] = v[k];
-            }
-        } else if (op == MLMC_X_STORE) {
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const int64_t i = i0 + (int64_t)k * X_THREADS;
-                if (i < n) {
-                    out_f[(int64_t)ins.b * n + i] = x[k * X_THREADS];
-                    if (PAIR) out_c[(int64_t)ins.b * n + i] = x[(S + k) * X_THREADS];
+                    prev[k] = i < n ? row[i * ss] : 0.0;
                 }
             }
         } else if (op == MLMC_X_CONST) {
 #pragma unroll
-            for (int s = 0; s < SIDES * S; ++s) d[s * X_THREADS] = ins.imm;
-        } else if (op == MLMC_X_SELECT) {
-#pragma unroll
-            for (int k = 0; k < S; ++k) keep[k] = keep[k] && (x[k * X_THREADS] != 0.0);
+            for (int s = 0; s < V; ++s) prev[s] = ins.imm;
         } else if (op >= MLMC_X_LT && op <= MLMC_X_NE) {
-            double v[S];
+            double av[V], bv[V];
+            fetch<V>(av, imm_a, prev_a, ins.imm, prev, x);
+            fetch<V>(bv, imm_b, prev_b, ins.imm, prev, y);
 #pragma unroll
             for (int k = 0; k < S; ++k) {
-                bool r = compare(op, imm_a ? ins.imm : x[k * X_THREADS], imm_b ? ins.imm : y[k * X_THREADS]);
-                if (PAIR) r = compare(op, imm_a ? ins.imm : x[(S + k) * X_THREADS], imm_b ? ins.imm : y[(S + k) * X_THREADS]) && r;
-                v[k] = r ? 1.0 : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                d[k * X_THREADS] = v[k];
-                if (PAIR) d[(S + k) * X_THREADS] = v[k];
+                bool r = compare(op, av[k], bv[k]);
+                if (PAIR) r = compare(op, av[(V - S) + k], bv[(V - S) + k]) && r;
+                prev[k] = r ? 1.0 : 0.0;
+                if (PAIR) prev[(V - S) + k] = prev[k];
             }
         } else if ((op >= MLMC_X_ADD && op <= MLMC_X_FMOD) || op == MLMC_X_AND || op == MLMC_X_OR || op == MLMC_X_XOR) {
-            binary<PAIR, S, HEAVY>(op, d, x, y, imm_a, imm_b, ins.imm);
+            double av[V], bv[V];
+            fetch<V>(av, imm_a, prev_a, ins.imm, prev, x);
+            fetch<V>(bv, imm_b, prev_b, ins.imm, prev, y);
+            binary<V, HEAVY>(op, prev, av, bv);
         } else {
-            unary<PAIR, S, HEAVY>(op, d, x);
+            double av[V];
+            fetch<V>(av, false, prev_a, 0.0, prev, x);
+            unary<V, HEAVY>(op, prev, av);
+        }
+        if (write_back) {
+#pragma unroll
+            for (int s = 0; s < V; ++s) d[s * X_THREADS] = prev[s];
         }
     }
     if (keep_out) {
@@ -334,19 +362,27 @@ int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_reg
     if (n_instr < 1 || n_instr > MLMC_EXPR_MAX_INSTR) return fail("mlmc_expr_create: program length out of range");
     if (n_regs < 1 || n_regs > MLMC_EXPR_MAX_REGS) return fail("mlmc_expr_create: register count out of range");
     if (n_in_rows < 1 || n_out_rows < 1) return fail("mlmc_expr_create: a program needs input and output rows");
-    bool selects = false, heavy = false;
+    bool selects = false, heavy = false, produced = false;
     std::vector<char> written(n_regs, 0), stored(n_out_rows, 0);
     for (int k = 0; k < n_instr; ++k) {   // validate: the kernel trusts every index
         mlmc_expr_instr in = prog[k];
         const bool imm_a = (in.op & MLMC_X_IMM_A) != 0, imm_b = (in.op & MLMC_X_IMM_B) != 0;
+        const bool prev_a = (in.op & MLMC_X_A_PREV) != 0, prev_b = (in.op & MLMC_X_B_PREV) != 0;
+        const bool no_wb = (in.op & MLMC_X_NO_WB) != 0;
         in.op &= MLMC_X_OP_MASK;
         if (in.op >= MLMC_X_N_OPS) return fail("mlmc_expr_create: unknown opcode");
         const bool two_operands = (in.op >= MLMC_X_ADD && in.op <= MLMC_X_FMOD) || (in.op >= MLMC_X_LT && in.op <= MLMC_X_NE);
         if ((imm_a || imm_b) && (!two_operands || (imm_a && imm_b)))
             return fail("mlmc_expr_create: immediate operands are for arithmetic / comparison instructions, one per instruction");
-        const bool reads_a = in.op != MLMC_X_LOAD && in.op != MLMC_X_CONST && !imm_a;
-        const bool reads_b = (two_operands || in.op == MLMC_X_AND || in.op == MLMC_X_OR || in.op == MLMC_X_XOR) && !imm_b;
-        const bool writes = in.op != MLMC_X_STORE && in.op != MLMC_X_SELECT;
+        const bool uses_a = in.op != MLMC_X_LOAD && in.op != MLMC_X_CONST && !imm_a;
+        const bool uses_b = (two_operands || in.op == MLMC_X_AND || in.op == MLMC_X_OR || in.op == MLMC_X_XOR) && !imm_b;
+        const bool produces = in.op != MLMC_X_STORE && in.op != MLMC_X_SELECT;
+        if ((prev_a && !uses_a) || (prev_b && !uses_b) || ((prev_a || prev_b) && !produced))
+            return fail("mlmc_expr_create: a chained operand needs a register operand slot and an earlier result");
+        if (no_wb && !produces) return fail("mlmc_expr_create: only value-producing instructions can skip the write-back");
+        const bool reads_a = uses_a && !prev_a, reads_b = uses_b && !prev_b;
+        const bool writes = produces && !no_wb;
+        if (produces) produced = true;
         if (in.op == MLMC_X_LOAD && in.a >= n_in_rows) return fail("mlmc_expr_create: input row out of range");
         if (reads_a && (in.a >= n_regs || !written[in.a])) return fail("mlmc_expr_create: operand a reads an unset register");
         if (reads_b && (in.b >= n_regs || !written[in.b])) return fail("mlmc_expr_create: operand b reads an unset register");
@@ -437,10 +473,11 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
         tc = has_coarse ? e->d_tmp_c : nullptr;
         keep = e->d_keep;
     }
-    // samples per thread: two for the light kernel (measured best: 5.3-6.1 TB/s on copy / arithmetic programs), up to
-    // four for the ALU-bound libm kernel, as long as the register file of a block stays within 32 KB of LDS
+    // samples per thread: two (measured best for both kernels: 5.3-6.1 TB/s on copy / arithmetic programs; with four
+    // the light kernel loses occupancy and the libm kernel spills), as long as the register file of a block stays
+    // within 32 KB of LDS
     const int sides = has_coarse ? 2 : 1;
-    const int s_max = e->heavy ? 4 : 2;
+    const int s_max = 2;
     int S = 1;
     while (S < s_max && (size_t)e->n_regs * sides * (2 * S) * X_THREADS * sizeof(double) <= 32768) S *= 2;
     if (const char *force = getenv("MLMC_EXPR_SLOTS")) {   // tuning aid

@@ -31,7 +31,8 @@ _OP_NAMES = ["LOAD", "CONST", "STORE", "SELECT", "ADD", "SUB", "MUL", "DIV", "MO
 OP = {name: i for i, name in enumerate(_OP_NAMES)}
 MAX_REGS = 16
 MAX_INSTR = 4096
-IMM_A, IMM_B, OP_MASK = 0x4000, 0x8000, 0x3fff      # operand-is-immediate flags of include/mlmc_hip.h
+IMM_A, IMM_B, OP_MASK = 0x4000, 0x8000, 0x07ff      # operand-is-immediate flags of include/mlmc_hip.h
+A_PREV, B_PREV, NO_WB = 0x2000, 0x1000, 0x0800      # chaining flags: operand = latest result; result not written back
 _IMM_OK = {"ADD", "SUB", "MUL", "DIV", "MOD", "POW", "MAXIMUM", "MINIMUM", "FMAX", "FMIN", "ATAN2", "HYPOT", "FMOD",
            "LT", "LE", "GT", "GE", "EQ", "NE"}
 
@@ -214,7 +215,7 @@ def _lower(q, bld, memo):
     return out
 
 
-def _schedule(bld, out_rows):
+def _schedule(bld, out_rows, chain=True):
     """Order the SSA values row by row (a result row is stored as soon as it is complete, so few values are live at
     once) and assign registers by linear scan.  -> list of (op, dst, a, b, imm), n_regs"""
     order = []            # ("val", v) | ("store", v, row) | ("select", v)
@@ -257,21 +258,31 @@ def _schedule(bld, out_rows):
         emit(v)
         order.append(("store", v, row))
 
-    last_use = {}
-    for pos, item in enumerate(order):
+    def operands(v):
+        op = bld.nodes[v][0]
+        return () if op in ("LOAD", "CONST") else tuple(d for d in imm_form(v)[:2] if d >= 0)
+
+    # Chaining: the kernel keeps the result of the latest value-producing instruction in VGPRs.  A use of value d at
+    # position q is "chained" when d is that latest result (no other producer between); a value all of whose uses are
+    # chained needs no LDS register at all.
+    latest, producer_before = None, []
+    for item in order:
+        producer_before.append(latest)
         if item[0] == "val":
-            op = bld.nodes[item[1]][0]
-            if op not in ("LOAD", "CONST"):
-                for d in imm_form(item[1])[:2]:
-                    if d >= 0:
-                        last_use[d] = pos
-        else:
-            last_use[item[1]] = pos
+            latest = item[1]
+    uses = {}                                             # value -> [(position, chained)]
+    for pos, item in enumerate(order):
+        for d in (operands(item[1]) if item[0] == "val" else (item[1],)):
+            uses.setdefault(d, []).append((pos, chain and producer_before[pos] == d))
+    no_wb = {v for v, us in uses.items() if all(c for _, c in us)}
+    last_use = {v: max(p for p, c in us if not c) for v, us in uses.items() if v not in no_wb}
+
     free = list(range(MAX_REGS - 1, -1, -1))
     reg = {}
     n_regs = 0
     prog = []
     for pos, item in enumerate(order):
+        chained = producer_before[pos] if chain else None  # the value an operand may take from VGPRs here
         if item[0] == "val":
             v = item[1]
             op, a, b, imm = bld.nodes[v]
@@ -284,25 +295,33 @@ def _schedule(bld, out_rows):
                 a, b, flags, imm_value = imm_form(v)
                 if flags:
                     imm = imm_value
-                ra, rb = (reg[a] if a >= 0 else 0), (reg[b] if b >= 0 else 0)
+                if a >= 0 and a == chained:
+                    flags |= A_PREV
+                if b >= 0 and b == chained:
+                    flags |= B_PREV
+                ra = reg[a] if (a >= 0 and not flags & A_PREV) else 0
+                rb = reg[b] if (b >= 0 and not flags & B_PREV) else 0
                 for d in {a, b}:                        # operands that die here free their register for the result
-                    if d >= 0 and last_use.get(d) == pos:
-                        free.append(reg[d])
+                    if d >= 0 and d in reg and last_use.get(d) == pos:
+                        free.append(reg.pop(d))
+            if v in no_wb or v not in uses:              # lives in VGPRs only (or is never read)
+                prog.append((OP[op] | flags | NO_WB, 0, ra, rb, imm))
+                continue
             if not free:
                 raise NotLowerable("more than {} live values".format(MAX_REGS))
             reg[v] = free.pop()
             n_regs = max(n_regs, reg[v] + 1)
             prog.append((OP[op] | flags, reg[v], ra, rb, imm))
-            if v not in last_use:                        # never read (cannot happen for scheduled values, but be safe)
-                free.append(reg[v])
         else:
             v = item[1]
+            flags = A_PREV if v == chained else 0
+            ra = 0 if flags else reg[v]
             if item[0] == "store":
-                prog.append((OP["STORE"], 0, reg[v], item[2], 0.0))
+                prog.append((OP["STORE"] | flags, 0, ra, item[2], 0.0))
             else:
-                prog.append((OP["SELECT"], 0, reg[v], 0, 0.0))
-            if last_use.get(v) == pos:
-                free.append(reg[v])
+                prog.append((OP["SELECT"] | flags, 0, ra, 0, 0.0))
+            if v in reg and last_use.get(v) == pos:
+                free.append(reg.pop(v))
     if len(prog) > MAX_INSTR:
         raise NotLowerable("program of {} instructions".format(len(prog)))
     return prog, max(n_regs, 1)
@@ -322,8 +341,8 @@ class DevicePlan:
         # two trees with the same program over the same stored rows compute the same rows: cache identity
         self.signature = (tuple(self.prog), tuple(self.in_rows))
         # the tree only picks one stored row (the usual scalar quantity root[name][time][location][i])
-        self.is_row_copy = (len(self.prog) == 2 and self.prog[0][0] == OP["LOAD"] and self.prog[1][0] == OP["STORE"]
-                            and self.n_out == 1)
+        self.is_row_copy = (len(self.prog) == 2 and self.prog[0][0] & OP_MASK == OP["LOAD"]
+                            and self.prog[1][0] & OP_MASK == OP["STORE"] and self.n_out == 1)
 
     def instr_array(self):
         arr = (ExprInstr * len(self.prog))()
@@ -379,8 +398,9 @@ class DevicePlan:
             pass
 
 
-def lower(quantity):
-    """-> DevicePlan of a lowerable tree; raises NotLowerable otherwise.  Needs no GPU."""
+def lower(quantity, chain=True):
+    """-> DevicePlan of a lowerable tree; raises NotLowerable otherwise.  Needs no GPU.
+    chain=False: every value passes through the LDS register file (no MLMC_X_*_PREV / NO_WB flags; tests, tuning)."""
     leaf = quantity.get_quantity_storage()
     if leaf is None:
         raise NotLowerable("quantity without a storage")
@@ -393,7 +413,7 @@ def lower(quantity):
     rows = [bld.mat(v) for v in rows]
     if len(bld.in_rows) == 0:
         raise NotLowerable("quantity does not read the storage")
-    prog, n_regs = _schedule(bld, rows)
+    prog, n_regs = _schedule(bld, rows, chain=chain)
     return DevicePlan(leaf, bld.in_rows, len(rows), prog, n_regs, bool(bld.select_flags))
 
 
@@ -419,36 +439,40 @@ def run_reference(plan, stored, has_coarse=True):
     out = np.zeros((plan.n_out, n, s))
     keep = np.ones(n, dtype=bool)
     inv = {v: k for k, v in OP.items()}
+    table2, table1 = {}, {}
+    for k, v in _UFUNCS2.items():
+        table2.setdefault(v, k)
+    for k, v in _UFUNCS1.items():
+        table1.setdefault(v, k)
+    prev = None                                           # result of the latest value-producing instruction
     with np.errstate(all="ignore"):
         for op, dst, a, b, imm in plan.prog:
             name = inv[op & OP_MASK]
-            if op & (IMM_A | IMM_B):                      # the immediate stands in for a register
-                regs[-1] = np.full((n, s), imm)
-                a, b = (-1, b) if op & IMM_A else (a, -1)
+            va = np.full((n, s), imm) if op & IMM_A else (prev if op & A_PREV else regs.get(a))
+            vb = np.full((n, s), imm) if op & IMM_B else (prev if op & B_PREV else regs.get(b))
+            if name == "STORE":
+                out[b] = va
+                continue
+            if name == "SELECT":
+                keep &= va[:, 0] != 0
+                continue
             if name == "LOAD":
-                regs[dst] = stored[plan.in_rows[a]].astype(np.float64)
+                res = stored[plan.in_rows[a]].astype(np.float64)
             elif name == "CONST":
-                regs[dst] = np.full((n, s), imm)
-            elif name == "STORE":
-                out[b] = regs[a]
-            elif name == "SELECT":
-                keep &= regs[a][:, 0] != 0
+                res = np.full((n, s), imm)
             elif name in ("LT", "LE", "GT", "GE", "EQ", "NE"):
-                f = getattr(operator, name.lower())(regs[a], regs[b]).all(axis=1)
-                regs[dst] = np.repeat(f[:, None].astype(np.float64), s, axis=1)
+                f = getattr(operator, name.lower())(va, vb).all(axis=1)
+                res = np.repeat(f[:, None].astype(np.float64), s, axis=1)
             elif name in ("AND", "OR", "XOR"):
                 fn = {"AND": np.logical_and, "OR": np.logical_or, "XOR": np.logical_xor}[name]
-                regs[dst] = fn(regs[a] != 0, regs[b] != 0).astype(np.float64)
+                res = fn(va != 0, vb != 0).astype(np.float64)
             elif name == "NOT":
-                regs[dst] = (regs[a] == 0).astype(np.float64)
+                res = (va == 0).astype(np.float64)
+            elif name in table2:
+                res = table2[name](va, vb)
             else:
-                table2, table1 = {}, {}
-                for k, v in _UFUNCS2.items():
-                    table2.setdefault(v, k)
-                for k, v in _UFUNCS1.items():
-                    table1.setdefault(v, k)
-                if name in table2:
-                    regs[dst] = table2[name](regs[a], regs[b])
-                else:
-                    regs[dst] = table1[name](regs[a])
+                res = table1[name](va)
+            prev = res
+            if not op & NO_WB:                            # a result that skips the write-back exists in `prev` only
+                regs[dst] = res
     return out[:, keep, :], keep

@@ -584,6 +584,45 @@ def test_device_tree_block_upload_in_estimates(hip, monkeypatch):
     qe.device_cache_clear()
 
 
+def test_expr_chaining_flags_on_device(hip):
+    """Programs with chained operands (results kept in VGPRs) and without give bit-identical rows on the device; the
+    C ABI rejects programs whose flags make no sense (the kernel trusts its program)."""
+    import ctypes as C
+    import torch
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from tests.test_lowering import _spec, expression_zoo, make_storage
+    st = make_storage((3000, 1100), chunk_size=None)
+    root = make_root_quantity(st, _spec())
+    dev = torch.device("cuda", 0)
+    for name, q in expression_zoo(root).items():
+        plans = [lowering.lower(q, chain=False), lowering.lower(q, chain=True)]
+        for chunk in st.chunks():
+            stored = st.sample_pairs_level(chunk)
+            got = []
+            for plan in plans:
+                rows = [torch.from_numpy(np.ascontiguousarray(stored[r])).to(dev) for r in plan.in_rows]
+                torch.cuda.synchronize()
+                f, c, _ = plan.evaluate(rows, has_coarse=(stored.shape[-1] == 2), n=stored.shape[1], sync=True)
+                got.append((f.cpu().numpy(), None if c is None else c.cpu().numpy()))
+            assert np.array_equal(got[0][0], got[1][0], equal_nan=True), name
+            if got[0][1] is not None:
+                assert np.array_equal(got[0][1], got[1][1], equal_nan=True), name
+    OP = lowering.OP
+    bad = {
+        "chained operand before any result": [(OP["NEG"] | lowering.A_PREV, 0, 0, 0, 0.0), (OP["STORE"], 0, 0, 0, 0.0)],
+        "store that skips its write-back": [(OP["LOAD"], 0, 0, 0, 0.0), (OP["STORE"] | lowering.NO_WB, 0, 0, 0, 0.0)],
+        "chained b of a unary": [(OP["LOAD"], 0, 0, 0, 0.0), (OP["NEG"] | lowering.B_PREV, 0, 0, 0, 0.0), (OP["STORE"], 0, 0, 0, 0.0)],
+        "register read after a skipped write-back": [(OP["LOAD"] | lowering.NO_WB, 0, 0, 0, 0.0), (OP["STORE"], 0, 0, 0, 0.0)],
+    }
+    for why, prog in bad.items():
+        arr = (lowering.ExprInstr * len(prog))()
+        for k, (op, dst, a, b, imm) in enumerate(prog):
+            arr[k].op, arr[k].dst, arr[k].a, arr[k].b, arr[k].imm = op, dst, a, b, imm
+        h = C.c_void_p()
+        assert hip.lib().mlmc_expr_create(arr, len(prog), 1, 1, 1, C.byref(h)) != 0, why
+
+
 def test_device_subsample_gather(hip):
     """mlmc_subsample_gather: every output column is a column of the input (same index for all rows and for fine and
     coarse), the draw is reproducible from the seed, indices are uniform; and the estimate over a sub-sampled quantity

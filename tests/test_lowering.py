@@ -65,7 +65,7 @@ def test_programs_read_only_the_rows_they_need_and_share_subexpressions():
     plan = lowering.lower(x)
     assert plan.in_rows == [4] and len(plan.prog) == 2 and plan.n_regs == 1          # LOAD, STORE
     plan = lowering.lower((x + y) * (x + y) + (x + y))
-    names = [lowering._OP_NAMES[p[0]] for p in plan.prog]
+    names = [lowering._OP_NAMES[p[0] & lowering.OP_MASK] for p in plan.prog]
     assert sorted(plan.in_rows) == [4, 12 + 1] and names.count("ADD") == 2 and names.count("LOAD") == 2
     plan = lowering.lower(root * 2.0)                    # 24 independent rows: stored one by one, few registers
     assert plan.n_out == 24 and plan.n_regs <= 3
@@ -73,7 +73,7 @@ def test_programs_read_only_the_rows_they_need_and_share_subexpressions():
     import ctypes as C
     assert C.sizeof(lowering.ExprInstr) == 16
     arr = plan.instr_array()
-    assert arr[0].op == lowering.OP["LOAD"] or arr[0].op == lowering.OP["CONST"]
+    assert arr[0].op & lowering.OP_MASK in (lowering.OP["LOAD"], lowering.OP["CONST"])
 
 
 def test_trees_that_are_not_per_sample_functions_fall_back():
@@ -196,3 +196,31 @@ def test_reference_quantity_tree_golden_host_and_program():
             assert prog.shape == want.shape and np.array_equal(prog, want, equal_nan=True), (name, "program")
             n_checked += 1
     assert n_checked == len(g8.files) - 2
+
+
+def test_chained_programs_keep_values_in_vgprs():
+    """The scheduler flags operands that are the latest result (A_PREV / B_PREV) and drops the LDS write-back of values
+    read only that way (NO_WB): fewer registers, same rows as the unchained program (both run through the NumPy
+    interpreter, which keeps a skipped value in `prev` only)."""
+    from mlmc_amd.quantity import lowering
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    st = make_storage((50, 40, 30))
+    root = make_root_quantity(st, _spec())
+    x = root['length'][2]['10'][0]
+    y = root['width'][1]['30'][1]
+    q = (x - 0.1) * (x - 0.1) / (np.abs(y) + 1.0)
+    plain, chained = lowering.lower(q, chain=False), lowering.lower(q)
+    flags = lowering.A_PREV | lowering.B_PREV | lowering.NO_WB
+    assert not any(p[0] & flags for p in plain.prog) and plain.n_regs == 2
+    assert chained.n_regs == 1 and len(chained.prog) == len(plain.prog)
+    written = [p for p in chained.prog if not p[0] & lowering.NO_WB
+               and p[0] & lowering.OP_MASK not in (lowering.OP["STORE"], lowering.OP["SELECT"])]
+    assert len(written) == 1                                   # only (x - 0.1)^2 outlives its successor
+    assert chained.signature != plain.signature
+    for name, tree in expression_zoo(root).items():
+        a, b = lowering.lower(tree, chain=False), lowering.lower(tree)
+        assert b.n_regs <= a.n_regs, name
+        for chunk in st.chunks():
+            stored = st.sample_pairs_level(chunk)
+            (va, ka), (vb, kb) = lowering.run_reference(a, stored), lowering.run_reference(b, stored)
+            assert np.array_equal(va, vb, equal_nan=True) and np.array_equal(ka, kb), name

@@ -22,8 +22,11 @@ trees = {"copy": x, "central": (x - 2.0) * (x - 2.0), "ratio": (x * y) / (np.abs
          "deep": np.log1p(np.abs(np.tanh(x) * np.cos(y) + np.sqrt(np.square(y) + 1.0))) / (1.0 + np.exp2(np.negative(x))),
          "four_rows": root * 2.0 + 1.0, "select": x.select(x > 2.0, y < 3.0),
          "sum4": x + y + z + w}
+trees["bench6"] = (x - 0.1) * (x - 0.1) / (np.abs(y) + 1.0)
+trees["poly"] = ((x * 0.3 + 1.0) * x - 0.5) * x + (y * y - z) * (w + 2.0)
+CHAIN = os.environ.get("CHAIN", "1") == "1"
 for name, q in trees.items():
-    plan = lowering.lower(q)
+    plan = lowering.lower(q, chain=CHAIN)
     rr = [rows[r] for r in plan.in_rows]
     for _ in range(3):
         plan.evaluate(rr, True, n, sync=True)
