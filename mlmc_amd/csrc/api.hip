@@ -174,12 +174,17 @@ int mlmc_basis_create(const mlmc_basis_desc *d, mlmc_basis **out) {
             b->scale_c[i] = (double)c;
         }
     }
-    MLMC_HIP_CHECK(hipMalloc(&b->d_scale, sizeof(double) * R));
-    MLMC_HIP_CHECK(hipMemcpy(b->d_scale, b->scale_c.data(), sizeof(double) * R, hipMemcpyHostToDevice));
-    if (d->out_size > 0) {
+    hipError_t e = hipMalloc(&b->d_scale, sizeof(double) * R);
+    if (e == hipSuccess) e = hipMemcpy(b->d_scale, b->scale_c.data(), sizeof(double) * R, hipMemcpyHostToDevice);
+    if (e == hipSuccess && d->out_size > 0) {
         b->matrix.assign(d->matrix, d->matrix + (size_t)d->out_size * R);
-        MLMC_HIP_CHECK(hipMalloc(&b->d_matrix, sizeof(double) * b->matrix.size()));
-        MLMC_HIP_CHECK(hipMemcpy(b->d_matrix, b->matrix.data(), sizeof(double) * b->matrix.size(), hipMemcpyHostToDevice));
+        e = hipMalloc(&b->d_matrix, sizeof(double) * b->matrix.size());
+        if (e == hipSuccess)
+            e = hipMemcpy(b->d_matrix, b->matrix.data(), sizeof(double) * b->matrix.size(), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        mlmc_basis_destroy(b);
+        return fail(std::string("mlmc_basis_create: ") + hipGetErrorString(e));
     }
     *out = b;
     return 0;
@@ -205,10 +210,10 @@ int mlmc_basis_eval(const mlmc_basis *b, const double *x, int64_t n, int32_t siz
         return 0;
     }
     double *d_x = nullptr, *d_o = nullptr;
-    MLMC_HIP_CHECK(hipMalloc(&d_x, sizeof(double) * (size_t)n));
-    MLMC_HIP_CHECK(hipMalloc(&d_o, sizeof(double) * (size_t)n * size));
-    MLMC_HIP_CHECK(hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
-    int rc = launch_eval(b, d_x, n, size, d_o);
+    hipError_t e0 = hipMalloc(&d_x, sizeof(double) * (size_t)n);
+    if (e0 == hipSuccess) e0 = hipMalloc(&d_o, sizeof(double) * (size_t)n * size);
+    if (e0 == hipSuccess) e0 = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st);
+    int rc = e0 == hipSuccess ? launch_eval(b, d_x, n, size, d_o) : fail(std::string("mlmc_basis_eval: ") + hipGetErrorString(e0));
     if (!rc) {
         hipError_t e = hipMemcpyAsync(out, d_o, sizeof(double) * (size_t)n * size, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);

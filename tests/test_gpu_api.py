@@ -909,3 +909,77 @@ def test_device_tree_many_stored_rows(hip):
             if co is not None:
                 got = np.concatenate([got, co.cpu().numpy()[:, :, None]], axis=2)
             assert np.array_equal(got, host_chunk(q, chunk))
+
+
+def test_reference_style_moments_workflow(hip):
+    """The workflow of the reference's test/test_quantity_concept.py:526-648 (`test_moments`), statement by statement,
+    with the samples generated in HBM (SynthDeviceStorage + DeviceSampler instead of SynthSimulation + OneProcessPool +
+    HDF5; no failed samples) and every estimate on the device: adaptive loop to a target variance, moments at the bottom
+    / on the surface, linearity, central moments, covariance, single moment, sub-sample statistics."""
+    import scipy.stats as stats
+    from mlmc_amd import Monomial
+    from mlmc_amd import estimator as est_mod
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.quantity.quantity_estimate import estimate_mean, moments, covariance, moment
+    from mlmc_amd.sampler import DeviceSampler
+    from mlmc_amd.sim.synth_device import SynthDeviceStorage, result_format
+    n_moments, n_levels = 3, 3
+    level_parameters = est_mod.determine_level_parameters(n_levels=n_levels, step_range=[0.5, 0.01])
+    storage = SynthDeviceStorage(level_parameters, [0] * n_levels)
+    sampler = DeviceSampler(storage, level_parameters)
+    true_domain = stats.norm().ppf([0.0001, 0.9999])
+    moments_fn = Monomial(n_moments, true_domain)
+    sampler.set_initial_n_samples([100, 60, 15])
+    sampler.schedule_samples()
+    sampler.ask_sampling_pool_for_samples()
+    root_quantity = make_root_quantity(storage=storage, q_specs=result_format())
+    root_quantity_mean = estimate_mean(root_quantity)
+    estimator = est_mod.Estimate(root_quantity, sample_storage=storage, moments_fn=moments_fn)
+    target_var = 1e-2
+    variances, n_ops = estimator.estimate_diff_vars_regression(sampler._n_scheduled_samples)
+    n_estimated = est_mod.estimate_n_samples_for_target_variance(target_var, variances, n_ops, n_levels=sampler.n_levels)
+    rounds = 0
+    while not sampler.process_adding_samples(n_estimated, 0, 0.1):
+        variances, n_ops = estimator.estimate_diff_vars_regression(sampler._n_scheduled_samples)
+        n_estimated = est_mod.estimate_n_samples_for_target_variance(target_var, variances, n_ops, n_levels=sampler.n_levels)
+        rounds += 1
+        assert rounds < 200
+
+    moments_quantity = moments(root_quantity, moments_fn=moments_fn, mom_at_bottom=True)       # values at the bottom
+    moments_mean = estimate_mean(moments_quantity)
+    values_mean = moments_mean['length'][1]['10'][0]
+    assert np.allclose(values_mean.mean[:2], [1, 0.5], atol=1e-2)
+    assert np.all(values_mean.var < target_var)
+
+    new_moments_mean = estimate_mean(moments_quantity + moments_quantity)
+    assert np.allclose(moments_mean.mean + moments_mean.mean, new_moments_mean.mean)
+
+    moments_mean_2 = estimate_mean(moments(root_quantity, moments_fn=moments_fn, mom_at_bottom=False))   # on the surface
+    first, second, third = moments_mean_2[0], moments_mean_2[1], moments_mean_2[2]
+    assert np.allclose(values_mean.mean, [first.mean[0], second.mean[0], third.mean[0]], atol=1e-4)
+
+    central_root_quantity = root_quantity - root_quantity_mean.mean                          # central moments
+    monomial_mom_fn = Monomial(n_moments, domain=true_domain, ref_domain=true_domain)
+    central_mean = estimate_mean(moments(central_root_quantity, moments_fn=monomial_mom_fn, mom_at_bottom=True))
+    central_value_mean = central_mean['length'][1]['10'][0]
+    assert np.isclose(central_value_mean.mean[0], 1, atol=1e-10)
+    assert np.isclose(central_value_mean.mean[1], 0, atol=1e-2)
+
+    cov_mean = estimate_mean(covariance(root_quantity, moments_fn=moments_fn, cov_at_bottom=True))
+    cov_value = cov_mean['length'][1]['10'][0]
+    assert np.allclose(values_mean.mean, cov_value.mean[:, 0])
+
+    value_mean = estimate_mean(moment(root_quantity, moments_fn=moments_fn, i=0))['length'][1]['10'][0]
+    assert len(value_mean.mean) == 1
+
+    iters, sample_vec = 300, [30, 15, 10]
+    chunks_means, chunks_vars, chunks_subsamples = [], [], []
+    for _ in range(iters):
+        sub = root_quantity.subsample(sample_vec)
+        sub_mean = estimate_mean(moments(sub, moments_fn=moments_fn, mom_at_bottom=True))['length'][1]['10'][0]
+        chunks_means.append(sub_mean.mean)
+        chunks_vars.append(sub_mean.var)
+        chunks_subsamples.append(sub_mean.n_samples)
+    assert np.allclose(np.mean(chunks_subsamples, axis=0), sample_vec, rtol=0.5)
+    assert np.allclose(np.mean(chunks_means, axis=0), values_mean.mean, atol=1e-2)
+    assert np.allclose(np.mean(chunks_vars, axis=0) / iters, values_mean.var, atol=1e-3)
