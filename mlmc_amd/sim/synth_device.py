@@ -38,15 +38,20 @@ def sample_seeds(level_id, first_sample, n):
     return out
 
 
-def generate_rows(level_id, first_sample, n, fine_step, coarse_step, rows, device=None, loc=0.0, scale=1.0):
+def generate_rows(level_id, first_sample, n, fine_step, coarse_step, rows, device=None, loc=0.0, scale=1.0, out=None):
     """Stored rows `rows` (indices 0..23) of samples first_sample .. first_sample + n - 1 of one level, as torch CUDA
-    tensors in the storage layout: [n, 2] (fine, coarse) when coarse_step != 0, else [n, 1]."""
+    tensors in the storage layout: [n, 2] (fine, coarse) when coarse_step != 0, else [n, 1].
+    out: existing contiguous tensors [n, width] to fill (complete in memory on torch's stream) instead of new ones."""
     import torch
     lib = _lib.lib()
     dev = torch.device("cuda", _lib._bound_device if device is None else device)
     width = 2 if coarse_step != 0 else 1
-    out = [torch.empty((int(n), width), dtype=torch.float64, device=dev) for _ in rows]
-    torch.cuda.current_stream(dev).synchronize()
+    if out is None:
+        out = [torch.empty((int(n), width), dtype=torch.float64, device=dev) for _ in rows]
+        torch.cuda.current_stream(dev).synchronize()
+    assert all(t.is_contiguous() and tuple(t.shape) == (int(n), width) for t in out)
+    if int(n) == 0:
+        return out
     row_ids = (C.c_int32 * len(rows))(*[int(r) for r in rows])
     ptrs = (C.c_void_p * len(rows))(*[t.data_ptr() for t in out])
     _lib.check(lib.mlmc_synth_generate(int(level_id), int(first_sample), int(n), float(fine_step), float(coarse_step),
@@ -66,6 +71,7 @@ class SynthDeviceStorage(SampleStorage):
         self._loc, self._scale = float(loc), float(scale)
         self._steps = [float(np.ravel(s)[0]) for s in level_steps]
         self._shard = shard
+        self._rows = {}       # (level, stored row) -> [tensor [capacity, width], generated samples, first sample index]
         self._set_counts(n_samples)
         assert len(self._steps) == len(self._n)
         self._chunk_size = chunk_size
@@ -122,13 +128,52 @@ class SynthDeviceStorage(SampleStorage):
     def _steps_of(self, level_id):
         return self._steps[level_id], (self._steps[level_id - 1] if level_id > 0 else 0.0)
 
+    def _resident_bytes(self):
+        return sum(ent[0].numel() * 8 for ent in self._rows.values())
+
+    def _level_row(self, level, stored_row):
+        """The stored row of a whole level, resident in HBM: generated once, extended in place when the level grows
+        (samples are a function of (level, index): an adaptive loop only ever generates the new ones)."""
+        import torch
+        n, first = self._n[level], self._first[level]
+        h_f, h_c = self._steps_of(level)
+        ent = self._rows.get((level, stored_row))
+        if ent is not None and (ent[2] != first or ent[1] > n):      # a shard whose slice moved: start over
+            ent = None
+        if ent is None:
+            ent = [generate_rows(level, first, n, h_f, h_c, [stored_row], loc=self._loc, scale=self._scale)[0], n, first]
+            self._rows[(level, stored_row)] = ent
+            return ent[0]
+        t, have = ent[0], ent[1]
+        if have < n:
+            if t.shape[0] < n:                                       # grow geometrically, keep what exists
+                _lib.check(_lib.lib().mlmc_synchronize())            # the old rows may still be being generated / read
+                grown = torch.empty((max(n, int(1.5 * t.shape[0])), t.shape[1]), dtype=torch.float64, device=t.device)
+                grown[:have].copy_(t[:have])
+                torch.cuda.current_stream(t.device).synchronize()    # the library writes / reads it on its own stream
+                ent[0] = t = grown
+            generate_rows(level, first + have, n - have, h_f, h_c, [stored_row], loc=self._loc, scale=self._scale,
+                          out=[t[have:n]])
+            ent[1] = n
+        return t[:n]
+
     def device_row(self, chunk_spec, stored_row):
-        """One stored row of a chunk, generated in HBM: torch CUDA tensor [n, 2] (level 0: [n, 1])."""
+        """One stored row of a chunk in HBM: torch CUDA tensor [n, 2] (level 0: [n, 1]).  Rows of a level stay resident
+        and are extended when the level grows, as long as the storage holds less than `resident_gb` (default: the device
+        cache budget MLMC_HIP_DEVICE_CACHE_GB); beyond that every request generates its chunk afresh."""
         level = int(chunk_spec.level_id)
         sl = chunk_spec.chunk_slice if chunk_spec.chunk_slice is not None else slice(0, self._n[level], 1)
+        from ..quantity.quantity_estimate import _DeviceChunkCache
+        width = 2 if level > 0 else 1
+        if (level, stored_row) in self._rows or self._resident_bytes() + self._n[level] * width * 8 <= _DeviceChunkCache.budget():
+            return self._level_row(level, stored_row)[sl.start:sl.stop]
         h_f, h_c = self._steps_of(level)
         return generate_rows(level, self._first[level] + sl.start, sl.stop - sl.start, h_f, h_c, [stored_row], loc=self._loc,
                              scale=self._scale)[0]
+
+    def release_rows(self):
+        """Free the resident rows (they are regenerated on the next read)."""
+        self._rows.clear()
 
     def sample_pairs_level(self, chunk_spec):
         """Host copy [24, n, 2|1] of a chunk (small chunks / tests; the estimators use device_row)."""
