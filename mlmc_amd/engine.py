@@ -217,9 +217,10 @@ def level_stats(n, s, sp):
     return l_means, l_vars
 
 
-def percentiles(values, q_percent):
+def percentiles(values, q_percent, nan_policy="omit"):
     """np.percentile(values[~isnan(values)], q_percent) evaluated on the device (radix select), bit-identical to NumPy's
-    "linear" method.  values: NumPy array or torch CUDA tensor (flattened)."""
+    "linear" method.  values: NumPy array or torch CUDA tensor (flattened).
+    nan_policy="propagate": NaN for every percentile when a NaN is present, as plain np.percentile(values, ...)."""
     q = _lib.as_f64(np.atleast_1d(q_percent))
     out = np.empty(q.size, dtype=np.float64)
     if isinstance(values, np.ndarray):
@@ -231,4 +232,6 @@ def percentiles(values, q_percent):
     n_valid = C.c_int64()
     _lib.check(_lib.lib().mlmc_percentiles(_lib.ptr(values), int(n), _lib.ptr(q), int(q.size), _lib.ptr(out), C.byref(n_valid),
                                            _lib.mem_kind(values)))
+    if nan_policy == "propagate" and n_valid.value < n:
+        out[:] = np.nan
     return out

@@ -182,18 +182,17 @@ class Estimate:
 
 
 def estimate_domain(quantity, sample_storage, quantile=None):
-    """Module-level variant (reference: :344-363): percentile range of the fine samples of every level."""
+    """Module-level variant (reference: :344-363): percentile range of the fine samples of every level -- the first
+    n_collected[0] samples of each (`ChunkSpec(level_id, n_samples=n_collected()[0])`), NaNs not removed (np.percentile
+    then yields NaN, :360).  The samples stay where the device wants them (quantity_estimate.fine_samples_for_device)."""
     if quantile is None:
         quantile = 0.01
     ranges = []
     for level_id in range(sample_storage.get_n_levels()):
         n0 = sample_storage.get_n_collected()[0]
         chunk_spec = next(sample_storage.chunks(level_id=level_id, n_samples=n0))
-        fine = np.squeeze(quantity.samples(chunk_spec)[..., 0])
-        if np.isnan(fine).any():
-            ranges.append(np.array([np.nan, np.nan]))       # the module-level variant does not drop NaNs (reference :360)
-        else:
-            ranges.append(engine.percentiles(fine, [100 * quantile, 100 * (1 - quantile)]))
+        fine = qe.fine_samples_for_device(quantity, chunk_spec)
+        ranges.append(engine.percentiles(fine, [100 * quantile, 100 * (1 - quantile)], nan_policy="propagate"))
     ranges = np.array(ranges)
     return np.min(ranges[:, 0]), np.max(ranges[:, 1])
 

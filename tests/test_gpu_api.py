@@ -306,6 +306,15 @@ def test_estimate_domain(hip):
     assert lo == ref[0] and hi == ref[1]
     lo2, hi2 = Estimate.estimate_domain(q, st)
     assert lo2 == lo and hi2 == hi
+    # module-level variant (estimator.py:344-363): every level's own fine samples, NaNs propagate as in np.percentile
+    clean = level_arrays([5000, 3000], steps, 1, 0)
+    st2 = _storage(clean, steps, _scalar_spec())
+    q2 = make_root_quantity(st2, _scalar_spec())['q'][1]['0'][0, 0]
+    per_level = np.array([np.percentile(clean[l][0][0], [1, 99]) for l in range(2)])
+    lo3, hi3 = estimate_domain(q2, st2, quantile=0.01)
+    assert lo3 == per_level[:, 0].min() and hi3 == per_level[:, 1].max()
+    lo4, hi4 = estimate_domain(q, st)                     # `levels` carries NaN samples
+    assert np.isnan(lo4) and np.isnan(hi4)
 
 
 def test_covariance_layouts_of_vector_quantity(hip):
