@@ -106,19 +106,21 @@ class LevelAccumulator:
         of torch CUDA tensors, shape [n] ([M, n] for vector quantities).  Single-process estimates only (no all-reduce).
         -> n[L], n_rm[L], s[L, K], sp[L, K]"""
         k = len(chunks)
-        levels = (C.c_int32 * k)(*[int(c[0]) for c in chunks])
-        fine = (C.c_void_p * k)(*[c[1].data_ptr() for c in chunks])
-        coarse = (C.c_void_p * k)(*[None if c[2] is None else c[2].data_ptr() for c in chunks])
-        ns = (C.c_int64 * k)(*[int(c[1].shape[-1]) for c in chunks])
+        key = tuple((int(c[0]), c[1].data_ptr(), 0 if c[2] is None else c[2].data_ptr(), int(c[1].shape[-1])) for c in chunks)
+        cached = getattr(self, "_est_args", None)
+        if cached is None or cached[0] != key:              # the argument arrays of a repeated estimate are reused
+            cached = self._est_args = (key, (C.c_int32 * k)(*[c[0] for c in key]), (C.c_void_p * k)(*[c[1] for c in key]),
+                                       (C.c_void_p * k)(*[c[2] or None for c in key]), (C.c_int64 * k)(*[c[3] for c in key]))
+        _, levels, fine, coarse, ns = cached
         L, K = self.n_levels, self.K
         bufs = getattr(self, "_est_out", None)
         if bufs is None:
-            bufs = self._est_out = (np.empty(L, dtype=np.int64), np.empty(L, dtype=np.int64),
-                                    np.empty((L, K), dtype=np.float64), np.empty((L, K), dtype=np.float64))
+            arrays = (np.empty(L, dtype=np.int64), np.empty(L, dtype=np.int64),
+                      np.empty((L, K), dtype=np.float64), np.empty((L, K), dtype=np.float64))
+            bufs = self._est_out = arrays + tuple(_lib.ptr(a) for a in arrays)
         self._keepalive = list(chunks)
-        n, n_rm, s, sp = bufs
-        _lib.check(_lib.lib().mlmc_accum_estimate(self._h, k, levels, fine, coarse, ns, _lib.DEVICE, _lib.ptr(n), _lib.ptr(n_rm),
-                                                  _lib.ptr(s), _lib.ptr(sp)))
+        n, n_rm, s, sp, p_n, p_rm, p_s, p_sp = bufs
+        _lib.check(_lib.lib().mlmc_accum_estimate(self._h, k, levels, fine, coarse, ns, _lib.DEVICE, p_n, p_rm, p_s, p_sp))
         self._keepalive = []
         return n.copy(), n_rm.copy(), s.copy(), sp.copy()
 
