@@ -57,6 +57,25 @@ def synth_device(level, n, steps, seed, device):
     return fine, coarse
 
 
+def preroll(step, ms_target, world, dist, torch, dev):
+    """Run `step` untimed for about ms_target (the same number of times on every rank: steps may hold a collective)."""
+    if ms_target <= 0:
+        return 0
+    probe = 5
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(probe):
+        step()
+    torch.cuda.synchronize()
+    per = torch.tensor([(time.perf_counter() - t0) / probe], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(per, op=dist.ReduceOp.MAX)
+    count = min(int(ms_target / 1e3 / max(float(per.item()), 1e-6)) + 1, 20000)
+    for _ in range(count):
+        step()
+    return probe + count
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +83,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll-ms", type=float, default=250.0,
+                    help="untimed load before the W warm-up steps: the shader clock of an idle MI355X needs ~70 ms of "
+                         "continuous work to reach its steady state (0 = none)")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: native libraries (the RCCL banner, amdgpu notices) write to fd 1 directly,
@@ -160,11 +182,13 @@ def main():
         torch.cuda.synchronize()
 
     import gc
-    for _ in range(args.warmup):
-        one_estimate()
-    # no cyclic-GC pauses inside the timed region (a gen-2 collection of the torch-sized heap costs ~40 ms)
+    # no cyclic-GC pauses inside the timed region (a gen-2 collection of the torch-sized heap costs ~40 ms); collected
+    # before the warm-up so that the timed steps follow the warm-up without an idle gap (an idle GPU drops its clock)
     gc.collect()
     gc.disable()
+    preroll_steps = preroll(one_estimate, args.preroll_ms, world, dist, torch, dev)
+    for _ in range(args.warmup):
+        one_estimate()
     # kernel-time bookkeeping of the timed region only
     acc.kernel_time()                                # drop the warm-up launches from the totals
     sync()
@@ -232,7 +256,7 @@ def main():
         roofline["note"] = "ds_add_f64 (LDS atomic) bound: 8 updates per sample pair into per-wave copies of the 2 R sums"
     out = {
         "metric": "moment-evals/sec (samples x n_moments)", "value": value, "unit": "moment-evals/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll_steps, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["workload"], "levels": L, "samples_per_level_per_gpu": n_l, "n_moments": R,
                    "basis": cfg.get("basis", "Legendre"), "estimate": cfg["mode"], "exchange": "all-reduce of [L,(2+2K)] partial sums" if world > 1 else "none"},
@@ -312,10 +336,11 @@ def tree_bench(args, cfg, world, rank, dev, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
     gc.collect()
     gc.disable()
+    preroll_steps = preroll(one_step, args.preroll_ms, world, dist, torch, dev)
+    for _ in range(args.warmup):
+        one_step()
     plan.kernel_time()
     acc.kernel_time()
     sync()
@@ -335,7 +360,7 @@ def tree_bench(args, cfg, world, rank, dev, dist):
     traffic, traffic_src = pmc_avg_bytes_per_dispatch(args.config, "k_expr")
     out = {
         "metric": "moment-evals/sec (samples x n_moments)", "value": world * L * n_l * R * args.steps / elapsed,
-        "unit": "moment-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "unit": "moment-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll_steps,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["workload"], "levels": L, "samples_per_level_per_gpu": n_l, "n_moments": R,

@@ -1,5 +1,6 @@
 // C-ABI entry points of libmlmc_hip.so (include/mlmc_hip.h): runtime, basis objects, accumulators.
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -23,7 +24,7 @@ int ensure(void **p, size_t *cap, size_t bytes) {
     if (bytes <= *cap && *p) return 0;
     if (*p) {
         // earlier launches on the stream may still use the old buffer
-        MLMC_HIP_CHECK(hipStreamSynchronize(rt().stream));
+        MLMC_HIP_CHECK(wait_stream(rt().stream));
         MLMC_HIP_CHECK(hipFree(*p));
         *p = nullptr;
         *cap = 0;
@@ -105,10 +106,26 @@ int mlmc_init(int device, int flags) {
     return 0;
 }
 
+}  // extern "C"
+
+namespace mlmc {
+hipError_t wait_stream(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) break;
+    }
+    return hipStreamSynchronize(st);   // long waits (covariance passes, uploads) sleep as usual
+}
+}  // namespace mlmc
+
+extern "C" {
+
 int mlmc_set_stream(void *stream) {
     Runtime &r = rt();
     if (!r.ready) return fail("mlmc_init has not been called (no HIP device bound)");
-    MLMC_HIP_CHECK(hipStreamSynchronize(r.stream));
+    MLMC_HIP_CHECK(wait_stream(r.stream));
     if (r.own_stream) (void)hipStreamDestroy(r.stream);
     r.stream = (hipStream_t)stream;      // NULL = the legacy default stream
     r.own_stream = false;
@@ -118,14 +135,14 @@ int mlmc_set_stream(void *stream) {
 int mlmc_synchronize(void) {
     Runtime &r = rt();
     if (!r.ready) return fail("mlmc_init has not been called (no HIP device bound)");
-    MLMC_HIP_CHECK(hipStreamSynchronize(r.stream));
+    MLMC_HIP_CHECK(wait_stream(r.stream));
     return 0;
 }
 
 void mlmc_shutdown(void) {
     Runtime &r = rt();
     if (!r.ready) return;
-    (void)hipStreamSynchronize(r.stream);
+    (void)wait_stream(r.stream);
     if (r.own_stream) (void)hipStreamDestroy(r.stream);
     r.stream = nullptr;
     r.ready = false;
@@ -206,7 +223,7 @@ int mlmc_basis_eval(const mlmc_basis *b, const double *x, int64_t n, int32_t siz
     hipStream_t st = rt().stream;
     if (mem_kind == MLMC_DEVICE) {
         if (int rc = launch_eval(b, x, n, size, out)) return rc;
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(wait_stream(st));
         return 0;
     }
     double *d_x = nullptr, *d_o = nullptr;
@@ -216,7 +233,7 @@ int mlmc_basis_eval(const mlmc_basis *b, const double *x, int64_t n, int32_t siz
     int rc = e0 == hipSuccess ? launch_eval(b, d_x, n, size, d_o) : fail(std::string("mlmc_basis_eval: ") + hipGetErrorString(e0));
     if (!rc) {
         hipError_t e = hipMemcpyAsync(out, d_o, sizeof(double) * (size_t)n * size, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = wait_stream(st);
         if (e != hipSuccess) rc = fail(std::string("mlmc_basis_eval copy back: ") + hipGetErrorString(e));
     }
     (void)hipFree(d_x);
@@ -293,7 +310,7 @@ int mlmc_accum_reset(mlmc_accum *a) {
 
 void mlmc_accum_destroy(mlmc_accum *a) {
     if (!a) return;
-    if (rt().ready) (void)hipStreamSynchronize(rt().stream);
+    if (rt().ready) (void)wait_stream(rt().stream);
     void *ptrs[] = {a->d_state, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c, a->d_mask, a->d_out, a->d_vals_f, a->d_vals_c};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -316,7 +333,7 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
     if (mem_kind == MLMC_HOST) {
         // staging buffers are reused across pushes: the previous push's kernels must have consumed them
         if (bytes > a->stage_cap) {
-            MLMC_HIP_CHECK(hipStreamSynchronize(st));
+            MLMC_HIP_CHECK(wait_stream(st));
             if (a->d_stage_f) (void)hipFree(a->d_stage_f);
             if (a->d_stage_c) (void)hipFree(a->d_stage_c);
             a->d_stage_f = a->d_stage_c = nullptr;
@@ -325,7 +342,7 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             MLMC_HIP_CHECK(hipMalloc(&a->d_stage_c, bytes));
             a->stage_cap = bytes;
         } else {
-            MLMC_HIP_CHECK(hipStreamSynchronize(st));
+            MLMC_HIP_CHECK(wait_stream(st));
         }
         MLMC_HIP_CHECK(hipMemcpyAsync(a->d_stage_f, fine, bytes, hipMemcpyHostToDevice, st));
         d_f = a->d_stage_f;
@@ -335,7 +352,7 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
         }
         // the caller may reuse its buffers as soon as push returns: pageable memory has been staged by the runtime at
         // this point, pinned memory has not -- wait for the copies (the kernels below still run asynchronously)
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(wait_stream(st));
     } else if (mem_kind != MLMC_DEVICE) {
         return fail("mlmc_accum_push: bad mem_kind");
     }
@@ -366,7 +383,7 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             const int64_t chunk = 1 << 18;
             const size_t need = sizeof(double) * (size_t)(n < chunk ? n : chunk) * R1;
             if (need > a->vals_cap) {
-                MLMC_HIP_CHECK(hipStreamSynchronize(st));
+                MLMC_HIP_CHECK(wait_stream(st));
                 if (a->d_vals_f) (void)hipFree(a->d_vals_f);
                 if (a->d_vals_c) (void)hipFree(a->d_vals_c);
                 a->d_vals_f = a->d_vals_c = nullptr;
@@ -404,7 +421,7 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
     const size_t nk = (size_t)L * a->K;
     if (a->host_outputs && mem_kind == MLMC_HOST) {
         // the grid reductions already wrote the finished rows of every pushed level into the pinned mirror
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(wait_stream(st));
         const int64_t *hn = (const int64_t *)a->h_out;
         const double *hs = (const double *)(hn + 2 * (size_t)L) + 2 * (size_t)L;
         const size_t K = (size_t)a->K;
@@ -429,11 +446,11 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
         MLMC_HIP_CHECK(hipMemcpyAsync(n_rm, a->d_out_n + L, sizeof(int64_t) * L, hipMemcpyDeviceToDevice, st));
         MLMC_HIP_CHECK(hipMemcpyAsync(s, a->d_out_s, sizeof(double) * nk, hipMemcpyDeviceToDevice, st));
         MLMC_HIP_CHECK(hipMemcpyAsync(sp, a->d_out_sp, sizeof(double) * nk, hipMemcpyDeviceToDevice, st));
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(wait_stream(st));
     } else {
         // one packed copy into the pinned mirror, then plain host copies into the caller's arrays
         MLMC_HIP_CHECK(hipMemcpyAsync(a->h_out, a->d_out, a->out_bytes, hipMemcpyDeviceToHost, st));
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(wait_stream(st));
         const int64_t *hn = (const int64_t *)a->h_out;
         const double *hs = (const double *)(hn + 2 * (size_t)L) + 2 * (size_t)L;
         std::memcpy(n, hn, sizeof(int64_t) * L);
@@ -475,7 +492,7 @@ int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind) {
     const size_t bytes = sizeof(double) * (2 * (size_t)a->n_levels + 2 * (size_t)a->n_levels * a->K);
     MLMC_HIP_CHECK(hipMemcpyAsync(packed, a->d_out_nd, bytes, mem_kind == MLMC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     if (mem_kind == MLMC_DEVICE) return 0;   // stream-ordered: the caller's collective on the same stream needs no host sync
-    MLMC_HIP_CHECK(hipStreamSynchronize(st));
+    MLMC_HIP_CHECK(wait_stream(st));
     return 0;
 }
 

@@ -36,6 +36,9 @@ struct Runtime {
     hipDeviceProp_t prop;
 };
 Runtime &rt();
+// Wait for the stream with a bounded busy poll before blocking: the runtime's own wait spins for ~50 us and then sleeps on
+// the completion interrupt, whose wake-up (20-60 us, more from a deep CPU idle state) would dominate a 0.2 ms estimate.
+hipError_t wait_stream(hipStream_t st);
 
 // ---- device-visible basis parameters (passed by value to kernels) -------------------------
 struct BasisParams {

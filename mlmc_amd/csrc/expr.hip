@@ -426,7 +426,7 @@ int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_reg
 
 void mlmc_expr_destroy(mlmc_expr *e) {
     if (!e) return;
-    if (rt().ready) (void)hipStreamSynchronize(rt().stream);
+    if (rt().ready) (void)wait_stream(rt().stream);
     void *ptrs[] = {e->d_prog, (void *)e->d_rows, e->d_tmp_f, e->d_tmp_c, e->d_keep, e->d_offsets};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -454,7 +454,7 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
         for (int r = 0; r < e->n_in; ++r) tab.p[r] = rows_in[r];
     } else {
         // the table of the previous call may still be read by its kernel: drain the stream, then overwrite it
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(wait_stream(st));
         MLMC_HIP_CHECK(hipMemcpy((void *)e->d_rows, rows_in, sizeof(double *) * e->n_in, hipMemcpyHostToDevice));
         d_rows = e->d_rows;
     }
@@ -529,7 +529,7 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
     hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(X_THREADS), 0, st, keep, e->d_offsets, nblk, n, e->n_out, tf, tc, fine_out,
                        has_coarse ? coarse_out : nullptr);
     MLMC_HIP_CHECK(hipGetLastError());
-    MLMC_HIP_CHECK(hipStreamSynchronize(st));
+    MLMC_HIP_CHECK(wait_stream(st));
     if (n_selected) *n_selected = *e->h_total;
     return 0;
 }

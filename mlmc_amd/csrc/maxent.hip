@@ -654,7 +654,7 @@ struct DevPool {
         static char *g_base = nullptr;
         static size_t g_cap = 0;
         if (bytes > g_cap) {
-            MLMC_HIP_CHECK(hipStreamSynchronize(rt().stream));
+            MLMC_HIP_CHECK(wait_stream(rt().stream));
             if (g_base) (void)hipFree(g_base);
             g_base = nullptr;
             g_cap = 0;
@@ -751,7 +751,7 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
     static double *h_stage = nullptr;
     static size_t h_stage_cap = 0;
     if (n_in + n_out > h_stage_cap) {
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(wait_stream(st));
         if (h_stage) (void)hipHostFree(h_stage);
         h_stage = nullptr;
         h_stage_cap = 0;
@@ -786,7 +786,7 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
         MLMC_HIP_CHECK(hipMemcpyAsync(d_endpts.p, pts, sizeof(pts), hipMemcpyHostToDevice, st));
         if (int rc = launch_eval(b, d_endpts.d(), 4, R1, d_endphi.d())) return rc;
         MLMC_HIP_CHECK(hipMemcpyAsync(phi.data(), d_endphi.p, sizeof(double) * 4 * R1, hipMemcpyDeviceToHost, st));
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(wait_stream(st));
         for (int i = 0; i < R1; ++i) {
             if (opts->decay_left) ed[i] = (phi[i] - phi[R1 + i]) / eps / sigma[i];
             if (opts->decay_right) ed[R1 + i] = (-phi[2 * R1 + i] + phi[3 * R1 + i]) / eps / sigma[i];
@@ -809,7 +809,7 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
         hipLaunchKernelGGL(k_me_axpy, dim3((R1 + 127) / 128), dim3(128), 0, st, d_lam.d(), d_lam.d(), 0.0, R1, d_outblk.p + 16);
         double *res = h_stage + n_in;
         MLMC_HIP_CHECK(hipMemcpyAsync(res, d_outblk.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, st));
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(wait_stream(st));
 #ifdef MLMC_PROF_COOP
         fprintf(stderr, "coop stamps (us): A %.1f | bar1 %.1f | B %.1f | bar2 %.1f | C %.1f = load %.1f + ldl %.1f + solve %.1f (NB %d QS %d R1 %d)\n", res[9], res[10] - res[9],
                 res[11] - res[10], res[12] - res[11], res[13] - res[12], res[14] - res[12], res[15] - res[14], res[13] - res[15], NB, QS, R1);
@@ -849,7 +849,7 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
         hipLaunchKernelGGL(k_me_solve, dim3(1), dim3(256), lds, st, d_H.d(), d_g.d(), R1, tau, d_p.d(), d_scal.d());
         MLMC_HIP_CHECK(hipGetLastError());
         MLMC_HIP_CHECK(hipMemcpyAsync(scal, d_scal.p, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
-        MLMC_HIP_CHECK(hipStreamSynchronize(st));
+        MLMC_HIP_CHECK(wait_stream(st));
         return 0;
     };
     {   // the Cholesky kernel needs up to 128*129*8 + 1 KiB of dynamic LDS
@@ -885,7 +885,7 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
                 if (int rc = eval_F(d_trial.d(), 0)) return rc;
                 double s2[8];
                 MLMC_HIP_CHECK(hipMemcpyAsync(s2, d_scal.p, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
-                MLMC_HIP_CHECK(hipStreamSynchronize(st));
+                MLMC_HIP_CHECK(wait_stream(st));
                 Ft = s2[0];
                 if (Ft == Ft && Ft <= F + 1e-4 * alpha * gp) accepted = true;
             } else {
@@ -913,7 +913,7 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
     MLMC_HIP_CHECK(hipMemcpyAsync(lambda_io, d_lam.p, sizeof(double) * R1, hipMemcpyDeviceToHost, st));
     if (grad_out) MLMC_HIP_CHECK(hipMemcpyAsync(grad_out, d_g.p, sizeof(double) * R1, hipMemcpyDeviceToHost, st));
     if (hess_out) MLMC_HIP_CHECK(hipMemcpyAsync(hess_out, d_H.p, sizeof(double) * (size_t)R1 * R1, hipMemcpyDeviceToHost, st));
-    MLMC_HIP_CHECK(hipStreamSynchronize(st));
+    MLMC_HIP_CHECK(wait_stream(st));
     info->nit = nit;
     info->success = success;
     info->fun = F;
@@ -959,7 +959,7 @@ int mlmc_density_eval(const mlmc_basis *b, const double *lambda, const double *s
     }
     MLMC_HIP_CHECK(hipGetLastError());
     if (mem_kind == MLMC_HOST) MLMC_HIP_CHECK(hipMemcpyAsync(out, d_o.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-    MLMC_HIP_CHECK(hipStreamSynchronize(st));
+    MLMC_HIP_CHECK(wait_stream(st));
     return 0;
 }
 
@@ -1001,7 +1001,7 @@ int mlmc_density_integrate(const mlmc_basis *b, const double *lambda, const doub
     }
     MLMC_HIP_CHECK(hipGetLastError());
     MLMC_HIP_CHECK(hipMemcpyAsync(out, d_o.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-    MLMC_HIP_CHECK(hipStreamSynchronize(st));
+    MLMC_HIP_CHECK(wait_stream(st));
     return 0;
 }
 

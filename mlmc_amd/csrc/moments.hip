@@ -78,7 +78,7 @@ int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, dou
         hipLaunchKernelGGL(k_apply_matrix, dim3((tot + 255) / 256), dim3(256), 0, st, d_tmp, b->d_matrix, n, bp.size, size, d_out);
         MLMC_HIP_CHECK(hipGetLastError());
         if (!scratch) {
-            MLMC_HIP_CHECK(hipStreamSynchronize(st));
+            MLMC_HIP_CHECK(wait_stream(st));
             MLMC_HIP_CHECK(hipFree(d_tmp));
         }
     }

@@ -107,7 +107,7 @@ static int select_ranks(const double *d_x, int64_t n, Plan plan, std::vector<int
             hipLaunchKernelGGL(k_select_hist, dim3(blocks), dim3(256), 0, st, d_x, n, pf, shift, width, pass == 0 ? 1 : 0, d_hist);
             MLMC_HIP_CHECK(hipGetLastError());
             MLMC_HIP_CHECK(hipMemcpyAsync(h_hist, d_hist, sizeof(unsigned int) * pf.n * SEL_BINS, hipMemcpyDeviceToHost, st));
-            MLMC_HIP_CHECK(hipStreamSynchronize(st));
+            MLMC_HIP_CHECK(wait_stream(st));
             for (int t = 0; t < pf.n; ++t) hists[g0 + t].assign(h_hist + (size_t)t * SEL_BINS, h_hist + (size_t)t * SEL_BINS + nbins);
         }
         if (pass == 0) {

@@ -163,7 +163,7 @@ extern "C" int mlmc_synth_seeds(int32_t level_id, int64_t first_sample, int64_t 
     MLMC_HIP_CHECK(hipMalloc(&d, sizeof(uint32_t) * (size_t)n));
     hipLaunchKernelGGL(k_synth_seeds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, rt().stream, (int)level_id, first_sample, n, d);
     hipError_t e = hipMemcpyAsync(seeds_host, d, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, rt().stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(rt().stream);
+    if (e == hipSuccess) e = wait_stream(rt().stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(std::string("mlmc_synth_seeds: ") + hipGetErrorString(e));
     return 0;
