@@ -152,16 +152,11 @@ def main():
     extra = {}
 
     chunks = [(l, data[l][0], data[l][1]) for l in range(L)]
-    single = world == 1 and os.environ.get("MLMC_HIP_FORCE_DIST") != "1"
 
     def one_estimate():
-        if single:
-            n, n_rm, s, sp = acc.estimate(chunks)     # reset + push of every level + finalize: one call of the C ABI
-        else:
-            acc.reset()
-            for l in range(L):
-                acc.push(l, data[l][0], data[l][1])
-            n, n_rm, s, sp = acc.finalize()           # RCCL all-reduce of the partial sums inside
+        # reset + push of every level + finalize: one call of the C ABI; with more than one rank the packed partial sums
+        # stay on the device and go through ONE RCCL all-reduce before the host reads them
+        n, n_rm, s, sp = acc.estimate(chunks)
         l_means, l_vars = level_stats(n, s, sp)
         mean = np.sum(l_means, axis=0)
         with np.errstate(all="ignore"):

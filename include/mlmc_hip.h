@@ -113,6 +113,11 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
 int mlmc_accum_estimate(mlmc_accum *a, int32_t n_chunks, const int32_t *levels, const double *const *fine,
                         const double *const *coarse, const int64_t *n_samples, int mem_kind, int64_t *n, int64_t *n_rm,
                         double *s, double *sp);
+/* The same with the results as mlmc_accum_finalize_packed leaves them (one fp64 buffer n | n_rm | s | sp in host or
+ * device memory): the rank-local half of a multi-GPU estimate, stream-ordered before the all-reduce when device. */
+int mlmc_accum_estimate_packed(mlmc_accum *a, int32_t n_chunks, const int32_t *levels, const double *const *fine,
+                               const double *const *coarse, const int64_t *n_samples, int mem_kind, double *packed,
+                               int packed_kind);
 /* Same results in ONE fp64 buffer [n(L) | n_rm(L) | s(L*K) | sp(L*K)] (counts as exact doubles): a single packed
  * all-reduce (RCCL) then carries everything a multi-GPU estimate has to exchange.  With MLMC_DEVICE the call is
  * asynchronous (stream-ordered); with MLMC_HOST it synchronises. */

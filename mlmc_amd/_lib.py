@@ -63,6 +63,7 @@ SIGNATURES = {
     "mlmc_accum_finalize": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mlmc_accum_finalize_packed": (C.c_int, [_vp, _vp, C.c_int]),
     "mlmc_accum_estimate": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "mlmc_accum_estimate_packed": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "mlmc_accum_kernel_time": (C.c_int, [_vp, _dp, _ip, _ip]),
     "mlmc_percentiles": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _ip, C.c_int]),
     "mlmc_maxent_solve": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.POINTER(MaxentOpts), _vp,

@@ -496,6 +496,16 @@ int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind) {
     return 0;
 }
 
+int mlmc_accum_estimate_packed(mlmc_accum *a, int32_t n_chunks, const int32_t *levels, const double *const *fine,
+                               const double *const *coarse, const int64_t *n_samples, int mem_kind, double *packed,
+                               int packed_kind) {
+    if (!a || n_chunks < 0 || (n_chunks > 0 && (!levels || !fine || !n_samples))) return fail("mlmc_accum_estimate_packed: null argument");
+    if (int rc = mlmc_accum_reset(a)) return rc;
+    for (int k = 0; k < n_chunks; ++k)
+        if (int rc = mlmc_accum_push(a, levels[k], fine[k], coarse ? coarse[k] : nullptr, n_samples[k], mem_kind)) return rc;
+    return mlmc_accum_finalize_packed(a, packed, packed_kind);
+}
+
 int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes) {
     if (!a) return fail("mlmc_accum_kernel_time: null argument");
     if (a->ev_used) {   // the event pairs are read lazily, here: wait for the last one, then add them up

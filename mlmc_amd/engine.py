@@ -101,10 +101,11 @@ class LevelAccumulator:
         _lib.check(_lib.lib().mlmc_accum_push(self._h, int(level), _lib.ptr(fine), _lib.ptr(coarse), int(n),
                                               _lib.mem_kind(fine)))
 
-    def estimate(self, chunks):
+    def estimate(self, chunks, group=None, reduce=True):
         """reset + push + finalize in one call of the C ABI (`mlmc_accum_estimate`): chunks = [(level, fine, coarse | None)]
-        of torch CUDA tensors, shape [n] ([M, n] for vector quantities).  Single-process estimates only (no all-reduce).
-        -> n[L], n_rm[L], s[L, K], sp[L, K]"""
+        of torch CUDA tensors, shape [n] ([M, n] for vector quantities).  With an initialised process group of more than
+        one rank the chunks are this rank's shard and the packed partial sums are all-reduced once
+        (`mlmc_accum_estimate_packed` + allreduce_partials).  -> n[L], n_rm[L], s[L, K], sp[L, K]"""
         k = len(chunks)
         key = tuple((int(c[0]), c[1].data_ptr(), 0 if c[2] is None else c[2].data_ptr(), int(c[1].shape[-1])) for c in chunks)
         cached = getattr(self, "_est_args", None)
@@ -113,16 +114,40 @@ class LevelAccumulator:
                                        (C.c_void_p * k)(*[c[2] or None for c in key]), (C.c_int64 * k)(*[c[3] for c in key]))
         _, levels, fine, coarse, ns = cached
         L, K = self.n_levels, self.K
+        self._keepalive = list(chunks)
+        if reduce and _dist_group_active(group):
+            packed, on_gpu = self._packed_buffer(group)
+            _lib.check(_lib.lib().mlmc_accum_estimate_packed(self._h, k, levels, fine, coarse, ns, _lib.DEVICE, _lib.ptr(packed),
+                                                             _lib.DEVICE if on_gpu else _lib.HOST))
+            out = unpack_partials(allreduce_partials(packed, group), L, K)
+            self._keepalive = []
+            return out
         bufs = getattr(self, "_est_out", None)
         if bufs is None:
             arrays = (np.empty(L, dtype=np.int64), np.empty(L, dtype=np.int64),
                       np.empty((L, K), dtype=np.float64), np.empty((L, K), dtype=np.float64))
             bufs = self._est_out = arrays + tuple(_lib.ptr(a) for a in arrays)
-        self._keepalive = list(chunks)
         n, n_rm, s, sp, p_n, p_rm, p_s, p_sp = bufs
         _lib.check(_lib.lib().mlmc_accum_estimate(self._h, k, levels, fine, coarse, ns, _lib.DEVICE, p_n, p_rm, p_s, p_sp))
         self._keepalive = []
         return n.copy(), n_rm.copy(), s.copy(), sp.copy()
+
+    def _packed_buffer(self, group):
+        """(packed fp64 buffer n | n_rm | s | sp where the collective wants it, lives on the GPU?).  With RCCL the library's
+        kernels move onto torch's stream: finalize -> all-reduce is stream-ordered, no host sync in between."""
+        import torch
+        import torch.distributed as dist
+        L, K = self.n_levels, self.K
+        on_gpu = dist.get_backend(group) == "nccl"
+        if on_gpu and not getattr(_lib, "_on_torch_stream", False):
+            torch.cuda.set_device(_lib._bound_device)
+            _lib.use_torch_stream()
+            _lib._on_torch_stream = True
+        dev = torch.device("cuda", _lib._bound_device) if on_gpu else torch.device("cpu")
+        packed = getattr(self, "_packed", None)
+        if packed is None or packed.device != dev:
+            packed = self._packed = torch.empty(2 * L + 2 * L * K, dtype=torch.float64, device=dev)
+        return packed, on_gpu
 
     def finalize(self, group=None, reduce=True):
         """-> n[L], n_rm[L] (int64), s[L, K], sp[L, K] (float64); all-reduced over ranks when distributed."""
@@ -139,19 +164,9 @@ class LevelAccumulator:
         return n, n_rm, s, sp
 
     def _finalize_distributed(self, group):
-        import torch
-        import torch.distributed as dist
-        L, K = self.n_levels, self.K
-        on_gpu = dist.get_backend(group) == "nccl"
-        if on_gpu and not getattr(_lib, "_on_torch_stream", False):
-            # one stream for kernels and collectives: finalize -> all-reduce is stream-ordered, no host sync in between
-            torch.cuda.set_device(_lib._bound_device)
-            _lib.use_torch_stream()
-            _lib._on_torch_stream = True
-        dev = torch.device("cuda", _lib._bound_device) if on_gpu else torch.device("cpu")
-        packed = torch.empty(2 * L + 2 * L * K, dtype=torch.float64, device=dev)     # n | n_rm | s | sp
+        packed, on_gpu = self._packed_buffer(group)
         _lib.check(_lib.lib().mlmc_accum_finalize_packed(self._h, _lib.ptr(packed), _lib.DEVICE if on_gpu else _lib.HOST))
-        return unpack_partials(allreduce_partials(packed, group), L, K)
+        return unpack_partials(allreduce_partials(packed, group), self.n_levels, self.K)
 
     def kernel_time(self):
         """(ms, launches, algorithmic bytes) of the accumulation kernels since create or the previous call
@@ -174,7 +189,10 @@ def allreduce_partials(packed, group=None):
         return packed.numpy()
     host = _pinned_like(packed)                         # one pinned landing buffer per size, reused
     host.copy_(packed, non_blocking=True)
-    torch.cuda.current_stream(packed.device).synchronize()
+    if getattr(_lib, "_on_torch_stream", False):        # the library shares torch's stream: its bounded busy poll is the
+        _lib.check(_lib.lib().mlmc_synchronize())        # cheaper wait (the runtime's sleeps on the completion interrupt)
+    else:
+        torch.cuda.current_stream(packed.device).synchronize()
     return host.numpy().copy()
 
 

@@ -496,6 +496,18 @@ def _sharded_worker(rank, world, port, N, steps, R, out_dir):
                 acc.push(l, f[0, lo:hi], None if c is None else c[0, lo:hi])
             n, n_rm, s, sp = acc.finalize()            # all-reduce over the two ranks inside
             np.savez(os.path.join(out_dir, f"{tag}_rank{rank}.npz"), n=n, n_rm=n_rm, s=s, sp=sp)
+            # the one-call form over device-resident shards (mlmc_accum_estimate_packed + the same all-reduce)
+            import torch
+            dev = torch.device("cuda", 0)
+            chunks = []
+            for l, (f, c) in enumerate(levels):
+                lo, hi = shard_bounds(f.shape[1], rank, world)
+                chunks.append((l, torch.from_numpy(f[0, lo:hi].copy()).to(dev),
+                               None if c is None else torch.from_numpy(c[0, lo:hi].copy()).to(dev)))
+            torch.cuda.synchronize()
+            again = acc.estimate(chunks)
+            for a, b in zip(again, (n, n_rm, s, sp)):
+                assert np.array_equal(a, b), tag
     finally:
         dist.destroy_process_group()
 
