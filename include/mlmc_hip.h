@@ -11,7 +11,8 @@
  * Conventions: every function returns 0 on success, non-zero on error (message through
  * mlmc_last_error(), thread-local).  The caller owns every buffer passed in; the library owns
  * its device scratch.  `mem_kind` says where a caller buffer lives (host or the bound device).
- * One process binds one device (one process per GPU); handles are not thread-safe.
+ * One process binds one device (one process per GPU) and the library works on ONE stream with shared workspaces:
+ * calls must not overlap in time (serialise them if several host threads use the library); handles are not thread-safe.
  * All floating point is IEEE fp64, all counts int64.  No CPU fallback exists: without a HIP
  * device every compute entry point fails.
  */
