@@ -56,11 +56,20 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int I = wave % T, kslice = wave / T;
 
-    v4f64 acc[NG][T];
+    // Small tiles (T <= 2, one term window): a wave owns a k-slice (a quarter of the batch's samples) and ALL T x T tiles.
+    // The A fragment of tile row I and the B fragment of tile column I are the same LDS words (lane -> (term 16 I +
+    // lane % 16, sample 4 ks + lane / 16) in both operand layouts), so one read of the fine / coarse values of the T
+    // row blocks feeds T x T MFMAs per Gram matrix -- a third of the LDS traffic of the row-tile mapping below, which at
+    // these tile sizes was as busy as the matrix pipe itself (1.5 KB of ds_read per MFMA against 2 KB per 64 cycles).
+    constexpr bool SLICED = (T <= 2) && !WIDE;
+    constexpr int TI = SLICED ? T : 1;
+    v4f64 acc[NG][TI][T];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[g][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[g][i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
     // phase-1 role of this lane
     const int n_eval_waves = PAIR ? BATCH / 32 : BATCH / 64;
@@ -123,6 +132,43 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
         }
         __syncthreads();
         // ---------------- phase 2: MFMA over the batch ----------------
+        if constexpr (SLICED) {
+            const int rowl = lane & 15;
+#pragma unroll
+            for (int kk = 0; kk < BATCH / 16; ++kk) {
+                const int col = 4 * (wave + 4 * kk) + (lane >> 4);
+                double d[T], sv[T], dd[T], ss[T], ds[T];
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    const double f = lds_f[(16 * i + rowl) * STRIDE + col];
+                    d[i] = sv[i] = f;
+                    if (PAIR) {
+                        const double c = lds_c[(16 * i + rowl) * STRIDE + col];
+                        d[i] = f - c;
+                        sv[i] = f + c;
+                    }
+                    if (MODE == 0) {
+                        dd[i] = d[i] * d[i];
+                        ss[i] = sv[i] * sv[i];
+                        ds[i] = d[i] * sv[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < T; ++j) {
+                        if (MODE == 0) {
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[i], sv[j], acc[0][i][j], 0, 0, 0);
+                            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[i], ss[j], acc[1][i][j], 0, 0, 0);
+                            if (PAIR) acc[NG - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ds[i], ds[j], acc[NG - 1][i][j], 0, 0, 0);
+                        } else {
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[i], MODE == 2 ? sv[j] : d[j], acc[0][i][j], 0, 0, 0);
+                        }
+                    }
+            }
+            __syncthreads();
+            continue;
+        }
         const int arow = 16 * I + (lane & 15);
         // fixed trip count -> fully unrolled: the compiler hoists the next steps' LDS reads above the MFMAs
 #pragma unroll
@@ -148,15 +194,15 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
                     sb = fb + cb;
                 }
                 if (MODE == 0) {
-                    acc[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, sb, acc[0][J], 0, 0, 0);
+                    acc[0][0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, sb, acc[0][0][J], 0, 0, 0);
                     if (PAIR) {
-                        acc[1][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sb * sb, acc[1][J], 0, 0, 0);
-                        acc[2][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, db * sb, acc[2][J], 0, 0, 0);
+                        acc[1][0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sb * sb, acc[1][0][J], 0, 0, 0);
+                        acc[2][0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, db * sb, acc[2][0][J], 0, 0, 0);
                     } else {
-                        acc[1][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, fb * fb, acc[1][J], 0, 0, 0);
+                        acc[1][0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, fb * fb, acc[1][0][J], 0, 0, 0);
                     }
                 } else {
-                    acc[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, MODE == 2 ? sb : db, acc[0][J], 0, 0, 0);
+                    acc[0][0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, MODE == 2 ? sb : db, acc[0][0][J], 0, 0, 0);
                 }
             }
         }
@@ -166,24 +212,25 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
     // ---------------- write the workgroup's partial tiles ----------------
     // partial row = (block, kslice); columns [g][row][col] with g in {G0, G1, G2} (MODE 0) or {G} (MODE 1)
     constexpr int NGOUT = (MODE == 0) ? 3 : 1;
-    double *__restrict__ prow = partials + ((int64_t)blockIdx.x * NSL + kslice) * (NGOUT * NT * NT);
+    // SLICED: one partial row per wave (its k-slice) holding all tiles; else one per (block, kslice), a wave writes row tile I
+    double *__restrict__ prow = partials + (SLICED ? ((int64_t)blockIdx.x * 4 + wave) : ((int64_t)blockIdx.x * NSL + kslice)) * (NGOUT * NT * NT);
 #pragma unroll
-    for (int J = 0; J < T; ++J) {
+    for (int Iw = 0; Iw < TI; ++Iw) {
+        const int It = SLICED ? Iw : I;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * I + (lane >> 4) + 4 * r;
-            const int col = 16 * J + (lane & 15);
-            if (MODE == 0) {
-                prow[0 * NT * NT + row * NT + col] = acc[0][J][r];
-                if (PAIR) {
-                    prow[1 * NT * NT + row * NT + col] = acc[1][J][r];
-                    prow[2 * NT * NT + row * NT + col] = acc[2][J][r];
-                } else {   // level 0: d = s = f  ->  G1 = G2 = (F.F)^T (F.F)
-                    prow[1 * NT * NT + row * NT + col] = acc[1][J][r];
-                    prow[2 * NT * NT + row * NT + col] = acc[1][J][r];
+        for (int J = 0; J < T; ++J) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * It + (lane >> 4) + 4 * r;
+                const int col = 16 * J + (lane & 15);
+                if (MODE == 0) {
+                    prow[0 * NT * NT + row * NT + col] = acc[0][Iw][J][r];
+                    prow[1 * NT * NT + row * NT + col] = acc[1][Iw][J][r];
+                    // level 0: d = s = f  ->  G2 = G1 = (F.F)^T (F.F)
+                    prow[2 * NT * NT + row * NT + col] = acc[NG - 1][Iw][J][r];
+                } else {
+                    prow[row * NT + col] = acc[0][Iw][J][r];
                 }
-            } else {
-                prow[row * NT + col] = acc[0][J][r];
             }
         }
     }
@@ -476,7 +523,8 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
     const size_t width = (size_t)3 * NT * NT;
     int blocks = rt().n_cu * 2;
     if (n_batches < blocks) blocks = (int)n_batches;
-    if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * NSL * width)) return rc;
+    const int n_slices = T <= 2 ? 4 : NSL;             // partial rows per workgroup (k_cov_accum: SLICED)
+    if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * n_slices * width)) return rc;
     if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
     int64_t *pc = count ? a->d_pcounts : nullptr;
     const BasisParams &bp = a->basis->p;
@@ -495,7 +543,7 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
 #undef MLMC_COV_VALS
     MLMC_HIP_CHECK(hipGetLastError());
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
-    hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, a->d_partials, blocks * NSL, NT, 3, a->RP, 0,
+    hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, 3, a->RP, 0,
                        0, totals);
     MLMC_HIP_CHECK(hipGetLastError());
     if (count) {
@@ -526,7 +574,8 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
         for (int bj = 0; bj < NB; ++bj) {
             int blocks = rt().n_cu * ((bi != bj) ? 1 : 2);
             if (n_batches < blocks) blocks = (int)n_batches;
-            if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * NSL * width)) return rc;
+            const int n_slices = T <= 2 ? 4 : NSL;     // partial rows per workgroup (k_cov_accum: SLICED)
+            if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * n_slices * width)) return rc;
             if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
             const bool do_count = count && bi == 0 && bj == 0;
             int64_t *pc = do_count ? a->d_pcounts : nullptr;
@@ -551,7 +600,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
                 a->launches += 1;
                 a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
             }
-            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, a->d_partials, blocks * NSL, NT, NG,
+            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, NG,
                                a->RP, 64 * bi, 64 * bj, totals);
             MLMC_HIP_CHECK(hipGetLastError());
             if (do_count) {
