@@ -153,16 +153,21 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
                         ds[i] = d[i] * sv[i];
                     }
                 }
+            // symmetric Gram matrices (both operands the same vector: everything at level 0, G2 and D^T D with pairs) need
+            // only their upper tiles; the lower ones are mirrored when the partial tiles are written
 #pragma unroll
                 for (int i = 0; i < T; ++i)
 #pragma unroll
                     for (int j = 0; j < T; ++j) {
+                        const bool upper = j >= i;
                         if (MODE == 0) {
-                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[i], sv[j], acc[0][i][j], 0, 0, 0);
-                            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[i], ss[j], acc[1][i][j], 0, 0, 0);
-                            if (PAIR) acc[NG - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ds[i], ds[j], acc[NG - 1][i][j], 0, 0, 0);
+                            if (PAIR || upper) acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[i], sv[j], acc[0][i][j], 0, 0, 0);
+                            if (PAIR || upper) acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[i], ss[j], acc[1][i][j], 0, 0, 0);
+                            if (PAIR && upper) acc[NG - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ds[i], ds[j], acc[NG - 1][i][j], 0, 0, 0);
+                        } else if (MODE == 1 || !PAIR) {
+                            if (upper) acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[i], d[j], acc[0][i][j], 0, 0, 0);
                         } else {
-                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[i], MODE == 2 ? sv[j] : d[j], acc[0][i][j], 0, 0, 0);
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[i], sv[j], acc[0][i][j], 0, 0, 0);
                         }
                     }
             }
@@ -223,11 +228,27 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * It + (lane >> 4) + 4 * r;
                 const int col = 16 * J + (lane & 15);
+                // SLICED: lower tiles of the symmetric matrices were not computed: tile (J, I) transposed stands in
+                const bool low = SLICED && J < It;
+                // acc of tile (J, It) holds element (16 J + lane / 16 + 4 r, 16 It + lane % 16): it is written transposed
+                const int mirror = (16 * It + (lane & 15)) * NT + (16 * J + (lane >> 4) + 4 * r);
                 if (MODE == 0) {
-                    prow[0 * NT * NT + row * NT + col] = acc[0][Iw][J][r];
-                    prow[1 * NT * NT + row * NT + col] = acc[1][Iw][J][r];
-                    // level 0: d = s = f  ->  G2 = G1 = (F.F)^T (F.F)
-                    prow[2 * NT * NT + row * NT + col] = acc[NG - 1][Iw][J][r];
+                    if (PAIR) {
+                        prow[0 * NT * NT + row * NT + col] = acc[0][Iw][J][r];
+                        prow[1 * NT * NT + row * NT + col] = acc[1][Iw][J][r];
+                        if (!low) prow[2 * NT * NT + row * NT + col] = acc[NG - 1][Iw][J][r];
+                        else prow[2 * NT * NT + mirror] = acc[NG - 1][SLICED ? J : 0][It][r];
+                    } else if (!low) {   // level 0: d = s = f  ->  G2 = G1 = (F.F)^T (F.F)
+                        prow[0 * NT * NT + row * NT + col] = acc[0][Iw][J][r];
+                        prow[1 * NT * NT + row * NT + col] = acc[1][Iw][J][r];
+                        prow[2 * NT * NT + row * NT + col] = acc[1][Iw][J][r];
+                    } else {
+                        prow[0 * NT * NT + mirror] = acc[0][SLICED ? J : 0][It][r];
+                        prow[1 * NT * NT + mirror] = acc[1][SLICED ? J : 0][It][r];
+                        prow[2 * NT * NT + mirror] = acc[1][SLICED ? J : 0][It][r];
+                    }
+                } else if (low && (MODE == 1 || !PAIR)) {
+                    prow[mirror] = acc[0][SLICED ? J : 0][It][r];
                 } else {
                     prow[row * NT + col] = acc[0][Iw][J][r];
                 }

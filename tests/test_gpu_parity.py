@@ -769,6 +769,44 @@ def test_maxent_cooperative_launch_matches_the_step_by_step_solver(hip):
             assert i1.success == 0 and i1.nit <= max_it
 
 
+@pytest.mark.parametrize("R", [17, 24, 32])
+def test_covariance_two_tile_sizes(hip, R):
+    """17..32 moments: two 16-term tiles per dimension.  A wave owns a k-slice and all four tiles, and the lower tile of the
+    symmetric Gram matrices (everything at level 0, the third Gram matrix of a pair level) is not computed but mirrored:
+    level sums and their variances against the oracle, with NaN samples, for Legendre and Monomial; the mean-only mode
+    against the full one; transformed moments (values path) against the oracle."""
+    from mlmc_amd import Legendre, Monomial, TransformedMoments
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    levels = level_arrays([2301, 1500, 777], [0.5, 0.07, 0.01], 1, 19)
+    for cls, kind in ((Legendre, onp.LEGENDRE), (Monomial, onp.MONOMIAL)):
+        b = onp.Basis(kind, R, dom)
+        ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.covariance_rows(b, x))
+        n, n_rm, s, sp = _run_accum(cls(R, dom), levels, mode=LevelAccumulator.COV)
+        mean, var = _check_against(n, n_rm, s, sp, ref)
+        cov = mean.reshape(R, R)
+        assert np.array_equal(cov, cov.T) and np.array_equal(var.reshape(R, R), var.reshape(R, R).T)
+        acc = LevelAccumulator(cls(R, dom), len(levels), LevelAccumulator.COV, mean_only=True)
+        for l, (f, c) in enumerate(levels):
+            acc.push(l, f[0], None if c is None else c[0])
+        n1, r1, s1, sp1 = acc.finalize()
+        acc.close()
+        scale = np.sqrt(np.abs(sp) * n[:, None]) + 1e-300
+        assert np.array_equal(n1, n) and np.max(np.abs(s1 - s) / scale) < 1e-12
+    rng = np.random.default_rng(R)
+    mat = np.linalg.qr(rng.normal(size=(40, 40)))[0][:R]                      # R transformed moments of 40 Legendre ones
+    tm = TransformedMoments(Legendre(40, dom), mat)
+    n, n_rm, s, sp = _run_accum(tm, levels, mode=LevelAccumulator.COV)
+    base = onp.Basis(onp.LEGENDRE, 40, dom)
+
+    def rows(v):
+        phi = onp.eval_all(base, v.reshape(-1)).reshape(v.shape + (40,)) @ mat.T
+        phi[np.isnan(phi).any(axis=-1)] = np.nan
+        cov = np.einsum('...i,...j', phi, phi)
+        return cov.transpose((0, 3, 4, 1, 2)).reshape(R * R, v.shape[1], v.shape[2])
+    _check_against(n, n_rm, s, sp, onp.estimate_mean(to_chunks(levels), rows))
+
+
 @pytest.mark.parametrize("R", [8, 24, 64, 100])
 def test_mean_only_accumulators(hip, R):
     """MLMC_MODE_MEAN_ONLY (what Estimate.construct_density asks for): the level sums equal those of the full estimate to
