@@ -159,8 +159,11 @@ def main():
         n, n_rm, s, sp = acc.estimate(chunks)
         l_means, l_vars = level_stats(n, s, sp)
         mean = np.sum(l_means, axis=0)
-        with np.errstate(all="ignore"):
+        if n.min() > 0:
             var = np.sum(l_vars / n[:, None], axis=0)
+        else:
+            with np.errstate(all="ignore"):
+                var = np.sum(l_vars / n[:, None], axis=0)
         if acc_mom is not None:
             acc_mom.reset()
             for l in range(L):

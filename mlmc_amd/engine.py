@@ -226,14 +226,15 @@ def shard_bounds(n, rank, world_size):
 def level_stats(n, s, sp):
     """Per-level mean and variance of the differences (quantity_estimate.py:70-77): mean_l = s / n,
     var_l = (sp - s^2 / n) / (n - 1), inf where n <= 1.  n[L] int, s / sp [L, K]."""
-    nf = np.asarray(n, dtype=np.float64)[:, None]
+    n = np.asarray(n)
+    nf = n.astype(np.float64)[:, None]
     s = np.asarray(s)
+    if n.min() > 1:                                   # the usual case: no division by zero to silence, no level to patch
+        return s / nf, (sp - (s * s / nf)) / (nf - 1.0)
     with np.errstate(all="ignore"):
         l_means = s / nf
-        l_vars = (sp - (s ** 2 / nf)) / (nf - 1.0)
-    few = np.asarray(n) <= 1
-    if few.any():
-        l_vars[few] = np.inf
+        l_vars = (sp - (s * s / nf)) / (nf - 1.0)
+    l_vars[n <= 1] = np.inf
     return l_means, l_vars
 
 
