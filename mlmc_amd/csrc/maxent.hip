@@ -492,17 +492,31 @@ __global__ __launch_bounds__(COOP_THREADS) void k_me_coop(CoopArgs A) {
             const bool spd = bad_s == 0;
             double v0 = j0 < R1 ? -g[j0] : 0.0, v1 = j1 < R1 ? -g[j1] : 0.0;
             const double id0 = j0 < R1 ? y[j0] : 0.0, id1 = j1 < R1 ? y[j1] : 0.0;       // 1 / d_j
-            for (int i = 0; i < R1 && spd; ++i) {                 // L u = -g, then z = D^-1 u (z_i replaces u_i)
-                const double zi = readlane_f64(i < 64 ? v0 : v1, i & 63) * y[i];
-                if (j0 == i) v0 = zi;
-                if (j1 == i) v1 = zi;
-                if (j0 > i && j0 < R1) v0 = __builtin_fma(-Lm[j0 * ld + i], zi, v0);
-                if (j1 > i && j1 < R1) v1 = __builtin_fma(-Lm[j1 * ld + i], zi, v1);
-            }
-            for (int i = R1 - 1; i >= 0 && spd; --i) {            // L^T p = z: p_j = z_j - sum_{i > j} L_ij p_i, L_ij = Lm[i][j] / d_j
-                const double pi = readlane_f64(i < 64 ? v0 : v1, i & 63);
-                if (j0 < i) v0 = __builtin_fma(-Lm[i * ld + j0] * id0, pi, v0);
-                if (j1 < i) v1 = __builtin_fma(-Lm[i * ld + j1] * id1, pi, v1);
+            // the matrix entries and 1 / d_i of step i + 1 are requested while step i's broadcast chain runs: only the
+            // readlane -> fma dependency stays on the critical path, not an LDS round trip per step
+            const int jc0 = j0 < R1 ? j0 : 0, jc1 = j1 < R1 ? j1 : 0;
+            const bool two = R1 > 64;                              // lanes carry a second entry only beyond 64 moments
+            if (spd) {
+                double a0 = Lm[jc0 * ld + 0], a1 = two ? Lm[jc1 * ld + 0] : 0.0, yi = y[0];
+                for (int i = 0; i < R1; ++i) {                     // L u = -g, then z = D^-1 u (z_i replaces u_i)
+                    const int in = i + 1 < R1 ? i + 1 : i;
+                    const double n0 = Lm[jc0 * ld + in], n1 = two ? Lm[jc1 * ld + in] : 0.0, yn = y[in];
+                    const double zi = readlane_f64(i < 64 ? v0 : v1, i & 63) * yi;
+                    if (j0 == i) v0 = zi;
+                    if (j1 == i) v1 = zi;
+                    if (j0 > i && j0 < R1) v0 = __builtin_fma(-a0, zi, v0);
+                    if (j1 > i && j1 < R1) v1 = __builtin_fma(-a1, zi, v1);
+                    a0 = n0; a1 = n1; yi = yn;
+                }
+                double b0 = Lm[(R1 - 1) * ld + jc0] * id0, b1 = two ? Lm[(R1 - 1) * ld + jc1] * id1 : 0.0;
+                for (int i = R1 - 1; i >= 0; --i) {                // L^T p = z: p_j = z_j - sum_{i > j} L_ij p_i, L_ij = Lm[i][j] / d_j
+                    const int in = i > 0 ? i - 1 : 0;
+                    const double n0 = Lm[in * ld + jc0] * id0, n1 = two ? Lm[in * ld + jc1] * id1 : 0.0;
+                    const double pi = readlane_f64(i < 64 ? v0 : v1, i & 63);
+                    if (j0 < i) v0 = __builtin_fma(-b0, pi, v0);
+                    if (j1 < i) v1 = __builtin_fma(-b1, pi, v1);
+                    b0 = n0; b1 = n1;
+                }
             }
             if (j0 < R1) pdir[j0] = v0;
             if (j1 < R1) pdir[j1] = v1;
