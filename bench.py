@@ -119,7 +119,7 @@ def main():
 
     from mlmc_amd import _lib, Legendre, Spline
     from mlmc_amd.engine import LevelAccumulator, level_stats
-    from oracle import oracle_np as onp   # checker + cpu_baseline leg only
+    from mlmc_amd.estimator import determine_level_parameters
 
     _lib.init(local_rank, _lib.FLAG_TIMING)
     dev = torch.device("cuda", local_rank)
@@ -135,7 +135,7 @@ def main():
             dist.destroy_process_group()
         return
     dom = (-3.7190164854556804, 3.7190164854556804)   # scipy.stats.norm().ppf([1e-4, 1 - 1e-4]) (test/test_run.py:71)
-    steps = [s[0] for s in onp.determine_level_parameters(L, [0.5, 0.01])] if L > 1 else [0.01]
+    steps = [s[0] for s in determine_level_parameters(L, [0.5, 0.01])] if L > 1 else [0.01]
     fn = Spline(R, dom) if cfg.get("basis") == "Spline" else Legendre(R, dom)
     mode = LevelAccumulator.MOMENTS if cfg["mode"] == "moments" else LevelAccumulator.COV
     acc = LevelAccumulator(fn, L, mode)
@@ -269,6 +269,7 @@ def main():
 
     # ---- CPU baseline + parity gate on a bounded sample (rank 0, N = 1 only) ---------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle_np as onp            # the checker: only this leg touches oracle/
         out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_stats)
     if dist.is_initialized():
         dist.barrier()
@@ -291,9 +292,9 @@ def tree_bench(args, cfg, world, rank, dev, dist):
     from mlmc_amd.quantity.quantity import make_root_quantity
     from mlmc_amd.quantity.quantity_spec import QuantitySpec
     from mlmc_amd.sample_storage import Memory
-    from oracle import oracle_np as onp
+    from mlmc_amd.estimator import determine_level_parameters
     L, n_l, R = cfg["L"], cfg["n_per_level"], cfg["R"]
-    steps = [s[0] for s in onp.determine_level_parameters(L, [0.5, 0.01])]
+    steps = [s[0] for s in determine_level_parameters(L, [0.5, 0.01])]
     # the tree, built through the reference-style API over a (tiny) storage with the same two stored rows
     spec = [QuantitySpec(name="q", unit="", shape=(2, 1), times=[1], locations=['0'])]
     st = Memory()
