@@ -253,7 +253,7 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp,
     }
 }
 
-// Small tiles (RT <= 8, the reference's everyday n_moments = 5..10): the work per sample is a few dozen instructions and
+// Small tiles (RT <= 16, the reference's everyday n_moments = 5..10): the work per sample is a few dozen instructions and
 // the kernel sits between the HBM and the issue roof, so what matters is memory-level parallelism -- four samples per
 // lane per trip (eight 8-byte loads in flight, issued a whole trip ahead) instead of two.  Common configuration only.
 template <int KIND, int RT, bool PAIR>
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
     for (int i = 0; i < RT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
     int n_keep = 0, n_rm = 0;
     const unsigned prio_mod = tab.prio_mod > 0 ? (unsigned)tab.prio_mod : 1u;
-    constexpr bool WIDE = RT <= 8 && T0C == 0;
+    constexpr bool WIDE = RT <= 16 && T0C == 0;
     if (PLAIN && WIDE) {
         if (sg.coarse) accum_samples_wide<KIND, RT, true>(bp, sg.fine, sg.coarse, sg.n, bid, sg.nblocks, s, sp, n_keep, n_rm);
         else accum_samples_wide<KIND, RT, false>(bp, sg.fine, sg.coarse, sg.n, bid, sg.nblocks, s, sp, n_keep, n_rm);
