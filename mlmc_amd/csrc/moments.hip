@@ -560,7 +560,7 @@ static int pick_rt(int kind, int n_terms, int t0) {
     if (t0 == 64) return n_terms <= 16 ? 16 : (n_terms <= 32 ? 32 : (n_terms <= 48 ? 48 : 64));
     if (t0 > 0) return 64;
     if (kind == MLMC_LEGENDRE) {
-        const int opts[] = {4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+        const int opts[] = {4, 6, 8, 10, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64};   // 5, 10: the reference's usual n_moments
         for (int o : opts)
             if (n_terms <= o) return o;
         return 64;
@@ -600,7 +600,8 @@ static int accum_dispatch(int op, bool plain, const BasisParams &bp, int rt_sel,
     switch (bp.kind) {
         case MLMC_LEGENDRE:
             switch (rt_sel) {
-                MLMC_RT_CASE(MLMC_LEGENDRE, 4); MLMC_RT_CASE(MLMC_LEGENDRE, 8); MLMC_RT_CASE(MLMC_LEGENDRE, 12);
+                MLMC_RT_CASE(MLMC_LEGENDRE, 4); MLMC_RT_CASE(MLMC_LEGENDRE, 6); MLMC_RT_CASE(MLMC_LEGENDRE, 8);
+                MLMC_RT_CASE(MLMC_LEGENDRE, 10); MLMC_RT_CASE(MLMC_LEGENDRE, 12);
                 MLMC_RT_CASE(MLMC_LEGENDRE, 16); MLMC_RT_CASE(MLMC_LEGENDRE, 20); MLMC_RT_CASE(MLMC_LEGENDRE, 24);
                 MLMC_RT_CASE(MLMC_LEGENDRE, 28); MLMC_RT_CASE(MLMC_LEGENDRE, 32); MLMC_RT_CASE(MLMC_LEGENDRE, 40);
                 MLMC_RT_CASE(MLMC_LEGENDRE, 48); MLMC_RT_CASE(MLMC_LEGENDRE, 56);
