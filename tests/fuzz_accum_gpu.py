@@ -54,6 +54,11 @@ for it in range(int(os.environ.get("ITERS", 150))):
         okc = np.array_equal(n, ref.n_samples) and np.array_equal(n_rm, ref.n_rm_samples)
         scale = np.sqrt(np.abs(ref.sums_sq) * np.maximum(ref.n_samples[:, None], 1)) + 1e-300
         fin = np.isfinite(ref.sums) & np.isfinite(ref.sums_sq)
+        if mode == LevelAccumulator.COV:
+            # a covariance row f_i f_j - c_i c_j is accumulated as (d_i s_j + s_i d_j) / 2: an entry far below the level's
+            # typical row can lose relative accuracy (levels of one or two samples); gate it on the level's rms row scale
+            lvl = np.sqrt(np.mean(np.where(fin, np.abs(ref.sums_sq), 0.0), axis=1, keepdims=True) * np.maximum(ref.n_samples[:, None], 1))
+            scale = np.maximum(scale, lvl)
         e1 = np.max(np.abs(s - ref.sums)[fin] / np.maximum(np.abs(ref.sums), scale)[fin]) if fin.any() else 0.0
         # sums of squares: relative to the entry, with a floor of 1e-3 of the level's largest one (the covariance variance
         # comes from three Gram matrices whose terms can cancel in a single entry when a level holds a handful of samples)
