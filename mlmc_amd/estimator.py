@@ -71,8 +71,9 @@ class Estimate:
         reg_vars = np.array(raw_vars, copy=True)
         n_levels = raw_vars.shape[0]
         if n_levels >= 3:
-            cols = [m for m in range(1, raw_vars.shape[1]) if not np.allclose(raw_vars[:, m], 0)]
-            if cols:
+            # moments whose level variances are all (close to) zero are left alone, as np.allclose(raw_vars[:, m], 0) decides it
+            cols = 1 + np.flatnonzero(~np.all(np.isclose(raw_vars[:, 1:], 0), axis=0))
+            if cols.size:
                 log_h = np.log(np.asarray(sim_steps, dtype=np.float64)[1:])
                 design = np.stack([np.ones(n_levels - 1), log_h, log_h ** 2], axis=1)
                 with np.errstate(all="ignore"):
