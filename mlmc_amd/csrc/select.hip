@@ -3,7 +3,8 @@
 // Reference: Estimate.estimate_domain (mlmc/estimator.py:275-302) removes NaNs from the fine samples of a level and
 // calls np.percentile(fine, [100 q, 100 (1 - q)]) (NumPy "linear" method: interpolation between the two neighbouring
 // order statistics).  Here the two neighbours are found exactly by a most-significant-digit radix select on an
-// order-preserving 64-bit key (11-bit digits, per-block LDS histograms, 6 passes over the data for all ranks), and the
+// order-preserving 64-bit key (11-bit digits, per-block LDS histograms; two digit passes over the data for all ranks, one
+// pass that collects the few values left under the 22-bit prefixes for a host finish -- six digit passes with heavy ties), and the
 // interpolation is done with NumPy's own formula, so the result is bit-identical to np.percentile.
 #include <algorithm>
 #include <cmath>
@@ -61,6 +62,27 @@ __global__ __launch_bounds__(256) void k_select_hist(const double *__restrict__ 
     }
 }
 
+// After two digit passes a prefix of 22 bits usually holds a handful of values: the keys under up to SEL_MAX_PREFIX prefixes
+// are appended to a small buffer (order irrelevant) and the selection finishes on the host -- three scans of the data
+// instead of six.  Heavily repeated values overflow `cap`; the caller then keeps going digit by digit.
+__global__ __launch_bounds__(256) void k_select_collect(const double *__restrict__ x, int64_t n, SelPrefixes pf, int hi_shift,
+                                                        unsigned long long *__restrict__ out, unsigned int *__restrict__ count,
+                                                        unsigned int cap) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = x[i];
+        if (v != v) continue;
+        const unsigned long long key = order_key(v);
+        const unsigned long long hi = key >> hi_shift;
+        bool hit = false;
+#pragma unroll
+        for (int t = 0; t < SEL_MAX_PREFIX; ++t) hit = hit || (t < pf.n && hi == pf.prefix[t]);
+        if (hit) {
+            const unsigned pos = atomicAdd(count, 1u);
+            if (pos < cap) out[pos] = key;
+        }
+    }
+}
+
 static double key_to_double(unsigned long long key) {
     unsigned long long u = (key >> 63) ? (key & 0x7fffffffffffffffull) : ~key;
     double d;
@@ -68,7 +90,8 @@ static double key_to_double(unsigned long long key) {
     return d;
 }
 
-// The ranks[0..nr) smallest (0-based, ascending or not) non-NaN values of d_x[0..n): six passes over the data in total
+// The ranks[0..nr) smallest (0-based, ascending or not) non-NaN values of d_x[0..n): three passes over the data (six with
+// heavy ties)
 // (one shared top-digit pass, then five passes that follow all distinct prefixes together).  ranks may be filled in
 // after the first pass: `plan(nv)` is called with the number of valid values and returns them.
 template <typename Plan>
@@ -120,6 +143,7 @@ static int select_ranks(const double *d_x, int64_t n, Plan plan, std::vector<int
             prefix.assign(ranks.size(), 0);
             k = ranks;
         }
+        std::vector<int64_t> under(ranks.size(), 0);      // values that share the rank's prefix after this pass
         for (size_t r = 0; r < ranks.size(); ++r) {
             const size_t u = pass == 0 ? 0 : (size_t)(std::find(uniq.begin(), uniq.end(), prefix[r]) - uniq.begin());
             const std::vector<unsigned int> &h = hists[u];
@@ -132,6 +156,51 @@ static int select_ranks(const double *d_x, int64_t n, Plan plan, std::vector<int
             if (digit < 0) return fail("radix select: inconsistent histogram");
             k[r] -= cum;
             prefix[r] = (prefix[r] << width) | (unsigned long long)digit;
+            under[r] = h[digit];
+        }
+        if (pass == 1) {   // 22 bits fixed: finish on the host when the candidates are few
+            constexpr unsigned CAP = 1u << 16;
+            static unsigned long long *d_cand = nullptr, *h_cand = nullptr;
+            static unsigned int *d_ccount = nullptr, *h_ccount = nullptr;
+            if (!d_cand) {
+                MLMC_HIP_CHECK(hipMalloc(&d_cand, sizeof(unsigned long long) * CAP));
+                MLMC_HIP_CHECK(hipMalloc(&d_ccount, sizeof(unsigned int)));
+                MLMC_HIP_CHECK(hipHostMalloc((void **)&h_cand, sizeof(unsigned long long) * CAP, hipHostMallocDefault));
+                MLMC_HIP_CHECK(hipHostMalloc((void **)&h_ccount, sizeof(unsigned int), hipHostMallocDefault));
+            }
+            std::vector<unsigned long long> up;            // distinct prefixes and the number of values under each
+            int64_t total = 0;
+            for (size_t r = 0; r < ranks.size(); ++r)
+                if (std::find(up.begin(), up.end(), prefix[r]) == up.end()) { up.push_back(prefix[r]); total += under[r]; }
+            if (total <= (int64_t)CAP) {
+                std::vector<unsigned long long> cand;
+                for (size_t g0 = 0; g0 < up.size(); g0 += SEL_MAX_PREFIX) {
+                    SelPrefixes pf;
+                    pf.n = (int)std::min<size_t>(SEL_MAX_PREFIX, up.size() - g0);
+                    for (int t = 0; t < SEL_MAX_PREFIX; ++t) pf.prefix[t] = t < pf.n ? up[g0 + t] : 0;
+                    MLMC_HIP_CHECK(hipMemsetAsync(d_ccount, 0, sizeof(unsigned int), st));
+                    hipLaunchKernelGGL(k_select_collect, dim3(blocks), dim3(256), 0, st, d_x, n, pf, shift, d_cand, d_ccount, CAP);
+                    MLMC_HIP_CHECK(hipGetLastError());
+                    MLMC_HIP_CHECK(hipMemcpyAsync(h_ccount, d_ccount, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                    MLMC_HIP_CHECK(wait_stream(st));
+                    const unsigned got = *h_ccount;
+                    if (got > CAP) return fail("radix select: candidate buffer overflow");
+                    if (got) {
+                        MLMC_HIP_CHECK(hipMemcpyAsync(h_cand, d_cand, sizeof(unsigned long long) * got, hipMemcpyDeviceToHost, st));
+                        MLMC_HIP_CHECK(wait_stream(st));
+                        cand.insert(cand.end(), h_cand, h_cand + got);
+                    }
+                }
+                for (size_t r = 0; r < ranks.size(); ++r) {
+                    std::vector<unsigned long long> mine;
+                    for (unsigned long long key : cand)
+                        if ((key >> shift) == prefix[r]) mine.push_back(key);
+                    if (k[r] < 0 || (size_t)k[r] >= mine.size()) return fail("radix select: inconsistent candidates");
+                    std::nth_element(mine.begin(), mine.begin() + k[r], mine.end());
+                    prefix[r] = mine[(size_t)k[r]];
+                }
+                break;                                      // prefix[r] now is the full key of rank r
+            }
         }
     }
     values.resize(ranks.size());

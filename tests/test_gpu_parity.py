@@ -467,6 +467,8 @@ def test_percentiles_bit_identical_to_numpy(hip):
     cases = [rng.normal(size=100003), rng.normal(size=7) * 1e-300, np.array([3.0]), np.array([2.0, -1.0]),
              np.concatenate([rng.normal(size=5000), [np.nan] * 17, [np.inf, -np.inf, 0.0, -0.0]]),
              np.round(rng.normal(size=20000), 1),                      # many ties
+             np.round(rng.normal(size=400000), 0),                     # ties beyond the host-finish buffer: all six digit passes
+             np.concatenate([np.full(300000, 1.5), rng.normal(size=1000)]),
              -np.abs(rng.lognormal(size=30011)) * 1e5]
     qs = [0.0, 1.0, 0.01, 25.0, 50.0, 99.0, 99.999, 100.0]
     for x in cases:
