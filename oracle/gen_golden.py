@@ -239,7 +239,7 @@ def g2_g3_g4():
             out2[f"{tag}_moment3_var"] = r.var
         # covariance (small N only: the reference materialises [2, M, N, R, R])
         if tag in ("L3", "L3nan", "L1"):
-            for R in (8, 16, 64):
+            for R in (8, 16, 24, 64):
                 Ncov = [min(n, 1500 if R < 64 else 300) for n in N]
                 arrs_c = [a[:n] for a, n in zip(arrs, Ncov)]
                 stc = make_storage(arrs_c, steps_ll, n_ops, spec)

@@ -177,7 +177,7 @@ def test_estimate_covariance_golden(hip, g2, tag):
     dom = tuple(g2["domain"])
     N, steps, nan_every = g2[f"{tag}_N"], g2[f"{tag}_steps"], int(g2[f"{tag}_nan_every"])
     levels = level_arrays(N, steps, 1, nan_every)
-    for R in (8, 16, 64):
+    for R in (8, 16, 24, 64):
         key = f"{tag}_cov{R}"
         Ncov = g3[key + "_Ncov"]
         lv = [(f[:, :k], None if c is None else c[:, :k]) for (f, c), k in zip(levels, Ncov)]

@@ -134,7 +134,7 @@ def test_estimate_mean_covariance(g2, tag):
     dom = tuple(g2["domain"])
     N, steps, nan_every = g2[f"{tag}_N"], g2[f"{tag}_steps"], int(g2[f"{tag}_nan_every"])
     chunks = _level_chunks(N, steps, 1, nan_every)
-    for R in (8, 16, 64):
+    for R in (8, 16, 24, 64):
         key = f"{tag}_cov{R}"
         Ncov = g3[key + "_Ncov"]
         ch = [[c[0][:, :n, :]] for c, n in zip(chunks, Ncov)]
