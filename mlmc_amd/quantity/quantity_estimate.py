@@ -472,7 +472,26 @@ def estimate_mean(quantity, group=None, variance=True):
         fine, coarse = pair
         if n_comp == 1:
             fine, coarse = fine[0], (None if coarse is None else coarse[0])
+        # Resident chunks are gathered and handed over in ONE call of the C ABI at the end (mlmc_accum_estimate: reset +
+        # pushes + finalize); as soon as a host chunk shows up -- it is staged through a reused device buffer and has to be
+        # pushed at once -- everything goes through push() in arrival order.
+        resident = (not pushed_directly and getattr(fine, "is_cuda", False) and fine.is_contiguous()
+                    and (coarse is None or (getattr(coarse, "is_cuda", False) and coarse.is_contiguous())))
+        if resident:
+            gathered.append((level_id, fine, coarse))
+            return
+        flush_gathered()
         acc.push(level_id, fine, coarse)
+
+    gathered = []
+    pushed_directly = False
+
+    def flush_gathered():
+        nonlocal pushed_directly
+        pushed_directly = True
+        for item in gathered:
+            acc.push(*item)
+        gathered.clear()
 
     def flush_level(level_id, pairs, keys):
         if not pairs:
@@ -510,7 +529,11 @@ def estimate_mean(quantity, group=None, variance=True):
     flush_level(current, pairs, keys)
     if acc is None:
         raise Exception("All samples were masked")
-    n_samples, n_rm_samples, sums, sums_sq = acc.finalize(group=group)
+    if gathered and not pushed_directly:
+        n_samples, n_rm_samples, sums, sums_sq = acc.estimate(gathered, group=group)
+    else:
+        flush_gathered()
+        n_samples, n_rm_samples, sums, sums_sq = acc.finalize(group=group)
     _acc_pool.give(fn, n_levels, mode, n_comp, acc, mean_only=not variance)
     if int(np.sum(n_samples)) == 0:
         raise Exception("All samples were masked")
