@@ -593,7 +593,9 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0);
     for (int bi = 0; bi < NB; ++bi)
         for (int bj = 0; bj < NB; ++bj) {
-            int blocks = rt().n_cu * ((bi != bj) ? 1 : 2);
+            // workgroups per CU: one for the two-window blocks (135 KB of LDS), four for a single 16-term tile (33 KB each:
+            // -11..15 % time against two), two otherwise
+            int blocks = rt().n_cu * ((bi != bj) ? 1 : (T == 1 ? 4 : 2));
             if (n_batches < blocks) blocks = (int)n_batches;
             const int n_slices = T <= 2 ? 4 : NSL;     // partial rows per workgroup (k_cov_accum: SLICED)
             if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * n_slices * width)) return rc;
