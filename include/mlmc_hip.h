@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MLMC_ABI_VERSION 1
+#define MLMC_ABI_VERSION 2   /* 2: strides in mlmc_expr_eval, chaining flags, mlmc_accum_estimate_packed */
 
 /* basis kinds -- mlmc/moments.py: Legendre :174-229, Monomial :111-130, Fourier :133-171;
  * IDENTITY = the quantity itself (estimate_mean of a plain quantity, quantity_estimate.py:22-80);

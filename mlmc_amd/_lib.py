@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLMC_HIP_LIB", os.path.join(_HERE, "libmlmc_hip.so"))   # env override: development builds
 
+ABI_VERSION = 2      # MLMC_ABI_VERSION of include/mlmc_hip.h
 LEGENDRE, MONOMIAL, FOURIER, IDENTITY, SPLINE = 0, 1, 2, 3, 4
 MODE_MOMENTS, MODE_COV = 0, 1
 MODE_MEAN_ONLY = 0x100
@@ -105,6 +106,9 @@ def load():
                 fn = getattr(lib, name)
                 fn.restype = res
                 fn.argtypes = args
+            if lib.mlmc_abi_version() != ABI_VERSION:
+                raise MlmcHipError("{} has ABI version {}, this package binds version {}: rebuild it "
+                                   "(make -C mlmc_amd/csrc)".format(LIB_PATH, lib.mlmc_abi_version(), ABI_VERSION))
             _lib = lib
     return _lib
 

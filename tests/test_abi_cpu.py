@@ -23,7 +23,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, "ctypes prototype missing for " + name
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.mlmc_abi_version() == 1
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mlmc_hip.h")).read()
+    declared = int(re.search(r"#define MLMC_ABI_VERSION (\d+)", hdr).group(1))
+    assert lib.mlmc_abi_version() == declared == _lib.ABI_VERSION
 
 
 def test_no_cpu_fallback_without_gpu():
