@@ -11,9 +11,11 @@ Harness-side accommodations (no edits to the reference):
     the absent h5py) is never executed; sub-modules are imported unmodified.
   * ``memoization.cached`` (absent third-party package, a pure result cache with no arithmetic)
     is replaced by a pass-through decorator that offers ``.cache_clear()``; used only for the
-    fixtures that go through ``mlmc.quantity`` / ``mlmc.estimator`` (G2, G3, G4, G7).
+    fixtures that go through ``mlmc.quantity`` / ``mlmc.estimator`` (G2, G3, G4, G7, G8, G9).
     G1, G5, G6 need no stand-in at all.
   * ``np.float = float`` (alias removed in NumPy 1.24, used by sample_storage.py:174).
+  * G9 only: ``Memory._save_successful`` is fed an object array (``np.array`` of ragged tuples raises on NumPy >= 1.24,
+    sample_storage.py:171) and the cost per sample is ``n_ops_estimate(step)`` instead of the pool's measured wall time.
 
 Usage:  python oracle/gen_golden.py   (writes tests/golden/)
 """
