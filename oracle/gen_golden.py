@@ -203,7 +203,7 @@ def g2_g3_g4():
         out2[f"{tag}_steps"] = np.array(steps)
         out2[f"{tag}_M"] = np.array(M)
         out2[f"{tag}_nan_every"] = np.array(nan_every)
-        for R in (5, 32, 64):
+        for R in (5, 10, 32, 64):
             if M > 1 and R > 5:
                 continue
             fn = mm.Legendre(R, dom)

@@ -56,7 +56,7 @@ def test_estimate_api_golden(hip, tag, chunk):
     st = _storage(levels, steps, _scalar_spec(), chunk)
     root = make_root_quantity(st, _scalar_spec())
     q = root['q'][1]['0'][0, 0]
-    for R in (5, 32, 64):
+    for R in (5, 10, 32, 64):
         fn = Legendre(R, dom)
         est = Estimate(q, st, fn)
         means, vars_ = est.estimate_moments(fn)

@@ -130,7 +130,7 @@ def test_estimate_moments_golden(hip, g2, tag):
     dom = tuple(g2["domain"])
     N, steps, nan_every = g2[f"{tag}_N"], g2[f"{tag}_steps"], int(g2[f"{tag}_nan_every"])
     levels = level_arrays(N, steps, 1, nan_every)
-    for R in (5, 32, 64):
+    for R in (5, 10, 32, 64):
         n, n_rm, s, sp = _run_accum(Legendre(R, dom), levels)
         key = f"{tag}_leg{R}_b1"
         assert np.array_equal(n, g2[key + "_n"]) and np.array_equal(n_rm, g2[key + "_n_rm"])

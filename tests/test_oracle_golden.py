@@ -100,7 +100,7 @@ def test_estimate_mean_moments(g2, tag):
     dom = tuple(g2["domain"])
     N, steps, M, nan_every = g2[f"{tag}_N"], g2[f"{tag}_steps"], int(g2[f"{tag}_M"]), int(g2[f"{tag}_nan_every"])
     chunks = _level_chunks(N, steps, M, nan_every)
-    for R in (5, 32, 64):
+    for R in (5, 10, 32, 64):
         if M > 1 and R > 5:
             continue
         b = onp.Basis(onp.LEGENDRE, R, dom)
