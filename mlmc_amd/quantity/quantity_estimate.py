@@ -240,6 +240,30 @@ def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache):
     return t
 
 
+def _block_layout(raw, n_rows_read):
+    """Can the chunk view raw [M_stored, n, 2|1] go to the device as one flat copy of the storage's [n][sides][M] records?
+    -> (span in doubles from the first to the last value, sample stride, side stride) or None (rows are uploaded one by
+    one: they already are contiguous [n][2] / [n] rows, the tree reads less than 1/8 of a wide record, or the view is not
+    a record array).  Pure layout arithmetic on shape and strides."""
+    m_total, n, width = raw.shape
+    if n == 0 or raw.dtype != np.float64 or any(st % 8 for st in raw.strides):
+        return None
+    sm, sn, sw = (st // 8 for st in raw.strides)
+    if m_total == 1:
+        sm = 1                                                   # the stride of a length-1 axis carries no meaning
+    if width == 1:
+        sw = 0
+    rows_are_ready = (sn == width and (width == 1 or sw == 1))   # raw[m] already is an [n][2] / [n] row
+    if rows_are_ready or (m_total > 1 and n_rows_read * 8 < m_total):
+        return None
+    if sm != 1 or sn < m_total * width or (width == 2 and sw < m_total):
+        return None                                              # not an [n][sides][M] record array
+    span = (n - 1) * sn + (width - 1) * sw + m_total              # doubles between the first and the last value
+    if span > 3 * raw.size:
+        return None
+    return span, sn, sw
+
+
 def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache):
     """The whole stored chunk as ONE device buffer in the storage's own [n][2][M] layout (reference Memory storage and
     HDF5 `collected_values`, sample_storage.py:169-184), when the host view allows it: -> (flat device tensor,
@@ -256,22 +280,11 @@ def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache):
     key = ("block", id(owner)) + chunk_key
     item = _device_cache.get(key) if use_cache else None
     raw = plan.leaf.samples(chunk_spec)                           # [M_stored, n, 2|1] view of the storage
+    layout = _block_layout(raw, len(plan.in_rows))
+    if layout is None or layout[0] * 8 > _DeviceChunkCache.budget() // 4:
+        return None
+    span, sn, sw = layout
     m_total, n, width = raw.shape
-    if n == 0 or raw.dtype != np.float64 or any(st % 8 for st in raw.strides):
-        return None
-    sm, sn, sw = (st // 8 for st in raw.strides)
-    if m_total == 1:
-        sm = 1                                                   # the stride of a length-1 axis carries no meaning
-    if width == 1:
-        sw = 0
-    rows_are_ready = (sn == width and (width == 1 or sw == 1))   # raw[m] already is an [n][2] / [n] row: plain row upload
-    if rows_are_ready or (m_total > 1 and len(plan.in_rows) * 8 < m_total):
-        return None
-    if sm != 1 or sn < m_total * width or (width == 2 and sw < m_total):
-        return None                                              # not an [n][sides][M] record array
-    span = (n - 1) * sn + (width - 1) * sw + m_total              # doubles between the first and the last value
-    if span > 3 * raw.size or span * 8 > _DeviceChunkCache.budget() // 4:
-        return None
     if item is None:
         flat = np.lib.stride_tricks.as_strided(raw, shape=(span,), strides=(8,))
         dev = torch.device("cuda", _lib_device())

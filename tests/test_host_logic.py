@@ -219,3 +219,39 @@ def test_device_sampler_follows_the_reference_scheduling():
     assert [int(v) for v in sampler.l_scheduled_samples()] == cases[-1]["rounds"][-1]["n_scheduled"]
     assert sampler.ask_sampling_pool_for_samples(timeout=0) == 1
     assert sampler.sample_range(1000, 10).tolist() == [1000, 316, 100, 32, 10]
+
+
+def test_block_upload_layout_decisions():
+    """quantity_estimate._block_layout: which host views of a storage chunk go up as one flat copy (strided LOAD on the
+    device) and with which strides; pure shape / stride arithmetic, checked by rebuilding the view from the flat span."""
+    from mlmc_amd.quantity.quantity_estimate import _block_layout
+    rng = np.random.default_rng(3)
+
+    def check(raw, n_rows_read, expect_block):
+        got = _block_layout(raw, n_rows_read)
+        assert (got is not None) == expect_block, (raw.shape, raw.strides, got)
+        if got is None:
+            return
+        span, sn, sw = got
+        flat = np.lib.stride_tricks.as_strided(raw, shape=(span,), strides=(8,))
+        m_total, n, width = raw.shape
+        for m in (0, m_total - 1):
+            for i in (0, n // 2, n - 1):
+                for side in range(width):
+                    assert flat[m + i * sn + side * sw] == raw[m, i, side]
+
+    store = rng.normal(size=(1000, 2, 24))                        # Memory / HDF5 layout [N, 2, M]
+    chunk = store[100:600]
+    check(chunk.transpose(2, 0, 1), 24, True)                     # a pair level, every row read
+    check(chunk.transpose(2, 0, 1), 3, True)                      # 3 of 24 rows: 3 * 8 >= 24
+    check(chunk.transpose(2, 0, 1), 2, False)                     # 2 of 24 rows: per-row uploads
+    check(chunk[:, :1, :].transpose(2, 0, 1), 24, True)           # level 0 view [n, 1, M] of the same records
+    one = rng.normal(size=(500, 2, 1))
+    check(one.transpose(2, 0, 1), 1, False)                       # M = 1 pairs: raw[0] already is an [n][2] row
+    check(one[:, :1, :].transpose(2, 0, 1), 1, True)              # M = 1 at level 0: fine values at stride 2
+    check(np.ascontiguousarray(chunk.transpose(2, 0, 1)), 24, False)      # a copy in [M][n][2] order: not a record array
+    check(chunk.transpose(2, 0, 1)[:, ::-1], 24, False)           # reversed samples
+    check(chunk.transpose(2, 0, 1)[:, ::7], 24, False)            # every 7th sample: the span would be 7x the data
+    check(chunk.transpose(2, 0, 1)[:, ::2], 24, True)             # every 2nd: still within 3x
+    check(chunk.transpose(2, 0, 1)[:, :0], 24, False)             # no samples
+    check(chunk.astype(np.float32).transpose(2, 0, 1), 24, False)
