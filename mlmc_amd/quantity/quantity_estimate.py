@@ -113,6 +113,7 @@ class _DeviceChunkCache:
         nbytes = fine.nbytes + (0 if coarse is None else coarse.nbytes)
         if nbytes > self.budget():
             return None
+        self.drop(key)
         while self._bytes + nbytes > self.budget() and self._items:
             _, (_, _, old, _) = self._items.popitem(last=False)
             self._bytes -= old
@@ -131,6 +132,7 @@ class _DeviceChunkCache:
         item = (fine, coarse, nbytes, owner)
         if nbytes > self.budget():
             return item
+        self.drop(key)                                   # a replaced entry gives its bytes back first
         while self._bytes + nbytes > self.budget() and self._items:
             _, (_, _, old, _) = self._items.popitem(last=False)
             self._bytes -= old

@@ -255,3 +255,34 @@ def test_block_upload_layout_decisions():
     check(chunk.transpose(2, 0, 1)[:, ::2], 24, True)             # every 2nd: still within 3x
     check(chunk.transpose(2, 0, 1)[:, :0], 24, False)             # no samples
     check(chunk.astype(np.float32).transpose(2, 0, 1), 24, False)
+
+
+def test_device_chunk_cache_accounting(monkeypatch):
+    """The LRU bookkeeping of the HBM chunk cache (no GPU: entries are stand-ins that only report their size)."""
+    from mlmc_amd.quantity.quantity_estimate import _DeviceChunkCache
+
+    class Fake:
+        def __init__(self, n):
+            self.n = n
+
+        def numel(self):
+            return self.n
+
+    monkeypatch.setenv("MLMC_HIP_DEVICE_CACHE_GB", str(1000 * 8 / 2 ** 30))     # room for 1000 doubles
+    cache = _DeviceChunkCache()
+    a, b = object(), object()
+    cache.put_tensors("k1", Fake(300), Fake(100), owner=a)
+    cache.put_tensors("k2", Fake(300), None, owner=b)
+    cache.put_tensors("k3", Fake(200), None, owner=a)
+    assert cache._bytes == 900 * 8 and list(cache._items) == ["k1", "k2", "k3"]
+    assert cache.get("k1") is not None and list(cache._items) == ["k2", "k3", "k1"]      # a hit renews the entry
+    cache.put_tensors("k4", Fake(350), None, owner=b)                                    # evicts the oldest entry, k2
+    assert list(cache._items) == ["k3", "k1", "k4"] and cache._bytes == 950 * 8
+    cache.put_tensors("k4", Fake(100), None, owner=b)                                    # replacing returns the old bytes
+    assert cache._bytes == 700 * 8
+    big = cache.put_tensors("k5", Fake(5000), None, owner=a)                             # over the budget: served, not kept
+    assert big[2] == 5000 * 8 and "k5" not in cache._items and cache._bytes == 700 * 8
+    cache.drop_owner(a)
+    assert list(cache._items) == ["k4"] and cache._bytes == 100 * 8
+    cache.clear()
+    assert cache._bytes == 0 and not cache._items and cache.get("k4") is None
