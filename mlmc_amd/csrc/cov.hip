@@ -596,7 +596,9 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
             // workgroups per CU: one for the two-window blocks (135 KB of LDS), four for a single 16-term tile (33 KB each:
             // -11..15 % time against two), two otherwise
             int blocks = rt().n_cu * ((bi != bj) ? 1 : (T == 1 ? 4 : 2));
-            if (n_batches < blocks) blocks = (int)n_batches;
+            // small chunks: at least four batches per workgroup -- every workgroup leaves NSL partial matrices behind and the
+            // reduction reads them all (a 24-component quantity of 10^5 samples spent more time there than in the MFMAs)
+            if ((n_batches + 3) / 4 < blocks) blocks = (int)((n_batches + 3) / 4);
             const int n_slices = T <= 2 ? 4 : NSL;     // partial rows per workgroup (k_cov_accum: SLICED)
             if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * n_slices * width)) return rc;
             if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
