@@ -467,22 +467,24 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum_t4(BasisParams bp,
     }
 }
 
-// totals[g][row][col] (leading dimension RP) += sum over partial rows, fixed order.
+// totals[g][row][col] (leading dimension RP) += sum over partial rows, fixed order.  16 columns per workgroup (one 128-byte
+// line of every partial row), 64 row groups: a three-Gram 16 x 16 tile set already gives 48 workgroups (64 columns per
+// workgroup left a 24-component quantity of small chunks waiting on 12 of them).
 __global__ __launch_bounds__(1024) void k_reduce_cov(const double *__restrict__ partials, int nrows, int NT, int NG, int RP,
                                                     int roff, int coff, double *__restrict__ totals) {
-    __shared__ double lds[16][64];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    __shared__ double lds[64][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int width = NG * NT * NT;
-    const int col = blockIdx.x * 64 + c;
+    const int col = blockIdx.x * 16 + c;
     double acc = 0.0;
     if (col < width)
-        for (int b = g; b < nrows; b += 16) acc += partials[(int64_t)b * width + col];
+        for (int b = g; b < nrows; b += 64) acc += partials[(int64_t)b * width + col];
     lds[g][c] = acc;
     __syncthreads();
     if (g == 0 && col < width) {
         double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v += lds[k][c];
+        for (int k = 0; k < 64; ++k) v += lds[k][c];
         const int gi = col / (NT * NT), rem = col % (NT * NT);
         const int row = roff + rem / NT, cc = coff + rem % NT;
         if (row < RP && cc < RP) totals[(int64_t)gi * RP * RP + (int64_t)row * RP + cc] += v;
@@ -564,7 +566,7 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
 #undef MLMC_COV_VALS
     MLMC_HIP_CHECK(hipGetLastError());
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
-    hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, 3, a->RP, 0,
+    hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, 3, a->RP, 0,
                        0, totals);
     MLMC_HIP_CHECK(hipGetLastError());
     if (count) {
@@ -625,7 +627,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
                 a->launches += 1;
                 a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
             }
-            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, NG,
+            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, NG,
                                a->RP, 64 * bi, 64 * bj, totals);
             MLMC_HIP_CHECK(hipGetLastError());
             if (do_count) {
