@@ -401,7 +401,8 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
                                                      d_mask ? d_mask + off : nullptr, m_n, count);
             }
         } else {
-            rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, count, a->mean_only ? 2 : 0);
+            // all components of a vector quantity in one launch (grid.y = component; they share the mask)
+            rc = m == 0 ? launch_cov_accum(a, level, 0, d_f, d_c, d_mask, n, count_in_kernel, a->mean_only ? 2 : 0, a->n_comp) : 0;
         }
         if (rc) return rc;
     }

@@ -115,7 +115,7 @@ int flush_moments(mlmc_accum *a);
 int launch_moments_finalize(mlmc_accum *a);
 // cov.hip
 int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
-                     int64_t n, bool count, int gram_mode);
+                     int64_t n, bool count, int gram_mode, int ncomp = 1);
 int launch_cov_finalize(mlmc_accum *a);
 int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_vf, const double *d_vc, const uint8_t *d_mask,
                            int64_t n, bool count);

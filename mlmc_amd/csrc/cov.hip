@@ -53,6 +53,12 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
     __shared__ double lds_cb[(WIDE && PAIR) ? NT * STRIDE : 1];
     __shared__ int ldc[4][2];
 
+    // blockIdx.y = component of a vector quantity ([M][n] arrays, one mask for all): its own samples and partial rows
+    fine += (int64_t)blockIdx.y * n;
+    if (PAIR) coarse += (int64_t)blockIdx.y * n;
+    partials += (int64_t)blockIdx.y * gridDim.x * ((T <= 2 && BI == BJ) ? 4 : 4 / T) * (((MODE == 0) ? 3 : 1) * (16 * T) * (16 * T));
+    if (blockIdx.y) pcounts = nullptr;
+
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int I = wave % T, kslice = wave / T;
 
@@ -459,6 +465,11 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum_t4(BasisParams bp,
     __shared__ double lds_c[PAIR ? 64 * COV_LDS_STRIDE : 1];
     __shared__ int ldc[2][2];
     (void)R;
+    // blockIdx.y = component of a vector quantity (see k_cov_accum): one partial row [3 or 1][64][64] per workgroup
+    fine += (int64_t)blockIdx.y * n;
+    if (PAIR) coarse += (int64_t)blockIdx.y * n;
+    partials += (int64_t)blockIdx.y * gridDim.x * (((MODE == 0) ? 3 : 1) * 64 * 64);
+    if (blockIdx.y) pcounts = nullptr;
     switch (threadIdx.x >> 6) {   // every wave runs its own specialisation (same barrier count in all of them)
         case 0: cov_t4_body<KIND, PAIR, MODE, BD, 0>(bp, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
         case 1: cov_t4_body<KIND, PAIR, MODE, BD, 1>(bp, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
@@ -471,10 +482,12 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum_t4(BasisParams bp,
 // line of every partial row), 64 row groups: a three-Gram 16 x 16 tile set already gives 48 workgroups (64 columns per
 // workgroup left a 24-component quantity of small chunks waiting on 12 of them).
 __global__ __launch_bounds__(1024) void k_reduce_cov(const double *__restrict__ partials, int nrows, int NT, int NG, int RP,
-                                                    int roff, int coff, double *__restrict__ totals) {
+                                                    int roff, int coff, double *__restrict__ totals, int64_t comp_stride) {
     __shared__ double lds[64][17];
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int width = NG * NT * NT;
+    partials += (int64_t)blockIdx.y * nrows * width;       // blockIdx.y = component: its partial rows, its totals
+    totals += (int64_t)blockIdx.y * comp_stride;
     const int col = blockIdx.x * 16 + c;
     double acc = 0.0;
     if (col < width)
@@ -499,29 +512,29 @@ __global__ void k_reduce_counts2(const int64_t *__restrict__ pcounts, int nblock
 }
 
 template <int KIND, int T, int MODE, int BI, int BJ>
-static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, const double *d_f, const double *d_c,
+static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, int ncomp, const double *d_f, const double *d_c,
                         const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
     hipStream_t st = rt().stream;
     if constexpr (T == 4 && BI == BJ) {   // diagonal 64 x 64 block: wave-specialised kernel (symmetric tiles used where they exist)
         if (pair)
-            hipLaunchKernelGGL((k_cov_accum_t4<KIND, true, MODE, BI>), dim3(blocks), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
+            hipLaunchKernelGGL((k_cov_accum_t4<KIND, true, MODE, BI>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
         else
-            hipLaunchKernelGGL((k_cov_accum_t4<KIND, false, MODE, BI>), dim3(blocks), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
+            hipLaunchKernelGGL((k_cov_accum_t4<KIND, false, MODE, BI>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
         MLMC_HIP_CHECK(hipGetLastError());
         return 0;
     }
     if (pair)
-        hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE, BI, BJ>), dim3(blocks), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
+        hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE, BI, BJ>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
     else
-        hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE, BI, BJ>), dim3(blocks), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
+        hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE, BI, BJ>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 template <int KIND, int MODE>
-static int launch_cov_kind(const BasisParams &bp, int T, int bi, int bj, bool pair, int blocks, const double *d_f,
+static int launch_cov_kind(const BasisParams &bp, int T, int bi, int bj, bool pair, int blocks, int ncomp, const double *d_f,
                            const double *d_c, const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
-#define MLMC_COV_ARGS bp, pair, blocks, d_f, d_c, d_mask, n, R, partials, pcounts
+#define MLMC_COV_ARGS bp, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, partials, pcounts
     if (T == 1) return launch_cov_t<KIND, 1, MODE, 0, 0>(MLMC_COV_ARGS);
     if (T == 2) return launch_cov_t<KIND, 2, MODE, 0, 0>(MLMC_COV_ARGS);
     if (bi == 0 && bj == 0) return launch_cov_t<KIND, 4, MODE, 0, 0>(MLMC_COV_ARGS);
@@ -567,7 +580,7 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
     MLMC_HIP_CHECK(hipGetLastError());
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
     hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, 3, a->RP, 0,
-                       0, totals);
+                       0, totals, (int64_t)0);
     MLMC_HIP_CHECK(hipGetLastError());
     if (count) {
         hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
@@ -577,7 +590,8 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
 }
 
 int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
-                     int64_t n, bool count, int gram_mode) {
+                     int64_t n, bool count, int gram_mode, int ncomp) {
+    // ncomp > 1: components comp .. comp + ncomp - 1 of a vector quantity ([M][n] arrays) in ONE launch (grid.y)
     const bool diff_gram_only = gram_mode == 1;   // gram_mode: 0 = G0, G1, G2; 1 = D^T D into the moments' Gram slot; 2 = G0 only
     if (n == 0) return 0;
     const int R = a->R;
@@ -602,7 +616,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
             // reduction reads them all (a 24-component quantity of 10^5 samples spent more time there than in the MFMAs)
             if ((n_batches + 3) / 4 < blocks) blocks = (int)((n_batches + 3) / 4);
             const int n_slices = T <= 2 ? 4 : NSL;     // partial rows per workgroup (k_cov_accum: SLICED)
-            if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * n_slices * width)) return rc;
+            if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * n_slices * width * ncomp)) return rc;
             if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
             const bool do_count = count && bi == 0 && bj == 0;
             int64_t *pc = do_count ? a->d_pcounts : nullptr;
@@ -610,9 +624,9 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
             if (timed) if (int rc = timing_begin(a)) return rc;
             int rc;
 #define MLMC_COV_DISPATCH(KIND)                                                                                               \
-    rc = gram_mode == 2 ? launch_cov_kind<KIND, 2>(bp, T, bi, bj, pair, blocks, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
-       : diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, bi, bj, pair, blocks, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
-                        : launch_cov_kind<KIND, 0>(bp, T, bi, bj, pair, blocks, d_f, d_c, d_mask, n, R, a->d_partials, pc)
+    rc = gram_mode == 2 ? launch_cov_kind<KIND, 2>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
+       : diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
+                        : launch_cov_kind<KIND, 0>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc)
             switch (bp.kind) {
                 case MLMC_LEGENDRE: MLMC_COV_DISPATCH(MLMC_LEGENDRE); break;
                 case MLMC_MONOMIAL: MLMC_COV_DISPATCH(MLMC_MONOMIAL); break;
@@ -625,10 +639,10 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
             if (timed) {
                 if (int rc2 = timing_end(a)) return rc2;
                 a->launches += 1;
-                a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
+                a->alg_bytes += (int64_t)n * (pair ? 16 : 8) * ncomp;
             }
-            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, NG,
-                               a->RP, 64 * bi, 64 * bj, totals);
+            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16), ncomp), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, NG,
+                               a->RP, 64 * bi, 64 * bj, totals, a->int_width);
             MLMC_HIP_CHECK(hipGetLastError());
             if (do_count) {
                 hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
