@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""Headline benchmark: moment-evals/s of one complete MLMC moment estimate on MI355X.
+"""Headline benchmark: moment-evals/s of one complete MLMC estimate on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5|6]
 
-N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
-(one rank per GPU, RCCL).  Workload at N = 1: BASELINE.json configs[1] -- 3 levels x 10^7 synthetic samples,
-Legendre n_moments = 32, mean + variance estimate; for N > 1 every rank holds its own 3 x 10^7 shard (weak
-scaling) and the per-level partial sums are all-reduced once per estimate.
+Defaults (no --config):
+  N = 1  BASELINE.json configs[2], the largest single-GPU configuration: 5 levels x 1e7 synthetic samples, Legendre
+         n_moments = 64, moment covariance mean + variance, level-variance regression and n_samples re-allocation
+         (reference: estimator.py:44-74,366-385).  The same JSON line carries three secondary blocks, each with its own
+         roofline: "moments_r64" (the stand-alone mean+var estimate on the same samples), "configs1" (BASELINE
+         configs[1]: 3 x 1e7, R = 32, mean+var) and "north_star" (1e8 samples x 64 moments, moments + covariance).
+  N > 1  BASELINE.json configs[3]: 5 levels x 1e8 samples sharded over the N ranks (strong scaling of the fixed 5e8
+         samples; launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`),
+         one packed all-reduce (RCCL) of the [L, 2 + 2 R^2] partial sums per estimate.
 
-A "step" = one complete estimate over data already resident in HBM: accumulator reset, push of every level
-(fused transform + recurrence + mask + level-difference accumulation kernels), finalize (grid reduction, RCCL
-all-reduce for N > 1, copy of the [L, R] sums to the host) and the O(L R) mean/variance formulas.
+A "step" = one complete estimate over data already resident in HBM: accumulator reset, push of every level (fused
+transform + recurrence + mask + level-difference accumulation kernels), finalize (grid reduction, all-reduce for
+N > 1, copy of the sums to the host) and the host formulas (level means / variances, MLMC totals; for the covariance
+configurations also the regression over the levels and the re-allocation, with the level variances of the moments
+read from row 0 of the covariance sums -- no second pass over the samples).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -26,6 +34,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector spec: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix spec
+DOMAIN = (-3.7190164854556804, 3.7190164854556804)   # scipy.stats.norm().ppf([1e-4, 1 - 1e-4]) (test/test_run.py:71)
 
 CONFIGS = {
     2: dict(L=3, n_per_level=10_000_000, R=32, mode="moments",
@@ -41,6 +50,14 @@ CONFIGS = {
     6: dict(L=3, n_per_level=10_000_000, R=32, mode="tree",
             workload="SURVEY 8(f) row 1: derived quantity (x - 0.1)^2 / (|y| + 1) of two stored rows, evaluated by the byte-code "
                      "kernel (3 levels x 1e7 samples per GPU), then the Legendre n_moments=32 mean+var estimate"),
+    # not selectable with --config: the N > 1 default and the north-star block of the N = 1 line
+    "sharded": dict(L=5, n_total_per_level=100_000_000, R=64, mode="cov",
+                    workload="BASELINE configs[3]: 5 levels x 1e8 synthetic samples sharded over the ranks, Legendre n_moments=64, "
+                             "moment covariance mean+var + level-variance regression + re-allocation; ONE all-reduce (RCCL) of the "
+                             "packed [L, 2 + 2 R^2] partial sums per estimate"),
+    "north_star": dict(L=5, n_per_level=20_000_000, R=64, mode="cov",
+                       workload="BASELINE north_star size: 1e8 synthetic samples (5 levels x 2e7) x 64 Legendre moments, "
+                                "moments mean+var estimate and moment covariance mean+var, 1 GPU"),
 }
 
 
@@ -57,32 +74,193 @@ def synth_device(level, n, steps, seed, device):
     return fine, coarse
 
 
-def preroll(step, ms_target, world, dist, torch, dev):
+class Ctx:
+    """What every measured block needs: ranks, device, collective handles."""
+
+    def __init__(self, world, rank, dev, dist, torch):
+        self.world, self.rank, self.dev, self.dist, self.torch = world, rank, dev, dist, torch
+
+    def sync(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def _reduce(self, values, op):
+        if self.world == 1:
+            return list(values)
+        on_gpu = self.dist.get_backend() == "nccl"
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.dev if on_gpu else "cpu")
+        self.dist.all_reduce(t, op=op)
+        return [float(v) for v in t]
+
+    def max_over_ranks(self, values):
+        return self._reduce(values, self.dist.ReduceOp.MAX)
+
+    def sum_over_ranks(self, values):
+        return self._reduce(values, self.dist.ReduceOp.SUM)
+
+
+def preroll(step, ms_target, ctx):
     """Run `step` untimed for about ms_target (the same number of times on every rank: steps may hold a collective)."""
     if ms_target <= 0:
         return 0
-    probe = 5
-    torch.cuda.synchronize()
+    probe = 3
+    ctx.torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(probe):
         step()
-    torch.cuda.synchronize()
-    per = torch.tensor([(time.perf_counter() - t0) / probe], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(per, op=dist.ReduceOp.MAX)
-    count = min(int(ms_target / 1e3 / max(float(per.item()), 1e-6)) + 1, 20000)
+    ctx.torch.cuda.synchronize()
+    per = ctx.max_over_ranks([(time.perf_counter() - t0) / probe])[0]
+    count = min(int(ms_target / 1e3 / max(per, 1e-6)) + 1, 20000)
     for _ in range(count):
         step()
     return probe + count
 
 
+def timed_loop(step, acc, steps, warmup, preroll_ms, ctx):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; elapsed = max over ranks.
+    -> (elapsed s, preroll steps, last result, [kernel ms, launches, algorithmic bytes] of `acc` inside the timed region)"""
+    # no cyclic-GC pauses inside the timed region (a gen-2 collection of the torch-sized heap costs ~40 ms); collected
+    # before the warm-up so that the timed steps follow the warm-up without an idle gap (an idle GPU drops its clock)
+    gc.collect()
+    gc.disable()
+    try:
+        pre = preroll(step, preroll_ms, ctx)
+        for _ in range(warmup):
+            step()
+        acc.kernel_time()                               # drop the warm-up launches from the totals
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        ctx.sync()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    # HIP events around every launch of the dominant kernel in the timed region, recorded on the library's stream and
+    # read back once, after the clock has stopped
+    kt = list(acc.kernel_time())
+    elapsed, k_ms = ctx.max_over_ranks([elapsed, kt[0]])
+    return elapsed, pre, res, [k_ms, int(kt[1]), int(kt[2])]
+
+
+def alg_flops(mode, R, pairs, singles):
+    """Algorithmic flops by the reference's operation count (SURVEY 8(d)): 14 R per pair, 8 R per level-0 sample;
+    the covariance adds 6 R^2 (three R x R x n contractions) per pair, 4 R^2 at level 0."""
+    if mode == "moments":
+        return (14 * R) * pairs + (8 * R) * singles
+    return (14 * R + 6 * R * R) * pairs + (8 * R + 4 * R * R) * singles
+
+
+def roofline_block(mode, basis, R, pairs_per_step, singles_per_step, kt, steps, config_key):
+    """Roofline of the dominant kernel of one block.  The BINDING roof is the top-level one: fp64 VALU for the moments
+    kernel at R >= 12 (28 flop/B at R = 32 against a ridge of 9.8), fp64 MFMA for the covariance kernel; the HBM figures
+    (algorithmic bytes / average launch duration) ride beside it under "hbm"."""
+    k_ms, launches, k_bytes = kt
+    per_step = max(launches // max(steps, 1), 1)
+    avg_launch_ms = k_ms / max(launches, 1)
+    gbs = (k_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+    hbm = {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    common = {"avg_launch_ms": round(avg_launch_ms, 5), "alg_bytes_per_launch": int(k_bytes / max(launches, 1)),
+              "launches_per_step": per_step}
+    if basis == "Spline":
+        kname = "k_spline_accum"
+        traffic, src = pmc_traffic(config_key, kname, per_step)
+        return dict(bound="hbm", **hbm, traffic=traffic, traffic_source=src, kernel=kname, **common,
+                    note="sparse accumulation (<= 8 of the R sums touched per sample pair): no dense flop count applies")
+    flops = alg_flops(mode, R, pairs_per_step, singles_per_step)
+    step_kernel_s = (k_ms / 1e3) / max(steps, 1)
+    tflops = flops / step_kernel_s / 1e12 if step_kernel_s > 0 else 0.0
+    if mode == "moments":
+        kname, bound, peak = "k_moments_accum", "valu_f64", FP64_VALU_PEAK_TFLOPS
+        if R < 12:                                      # HBM-bound below the ridge (SURVEY 8(d))
+            traffic, src = pmc_traffic(config_key, kname, per_step)
+            return dict(bound="hbm", **hbm, traffic=traffic, traffic_source=src, kernel=kname, **common)
+    else:
+        kname, bound, peak = "k_cov_accum", "mfma", FP64_MFMA_PEAK_TFLOPS
+    traffic, src = pmc_traffic(config_key, kname, per_step)
+    return dict(bound=bound, achieved=round(tflops, 3), peak=peak, unit="TFLOP/s", frac=round(tflops / peak, 4),
+                traffic=traffic, traffic_source=src, kernel=kname, alg_flops_per_step=int(flops), hbm=hbm, **common)
+
+
+def host_formulas(n, s, sp, level_stats):
+    l_means, l_vars = level_stats(n, s, sp)
+    with np.errstate(all="ignore"):
+        return l_means, l_vars, np.sum(l_means, axis=0), np.sum(l_vars / n[:, None], axis=0)
+
+
+def estimate_block(cfg, data, fn, steps_h, ctx, steps, warmup, preroll_ms, config_key, with_moments_pass=False):
+    """One measured workload on resident data -> result dict (value, ms_per_step, roofline, result_check, ...).
+    cfg["mode"] == "cov": covariance estimate + regression + re-allocation, the moments' level variances taken from the
+    covariance sums (engine.moments_from_covariance)."""
+    from mlmc_amd.engine import LevelAccumulator, level_stats, moments_from_covariance
+    from mlmc_amd.estimator import Estimate, estimate_n_samples_for_target_variance
+    L, R = cfg["L"], cfg["R"]
+    mode = LevelAccumulator.MOMENTS if cfg["mode"] == "moments" else LevelAccumulator.COV
+    acc = LevelAccumulator(fn, L, mode)
+    chunks = [(l, data[l][0], data[l][1]) for l in range(L)]
+    n_ops = [(1.0 / h) ** 2 * np.log(max(1.0 / h, 2.0)) for h in steps_h]      # synth_simulation.py:133-134
+    regress = Estimate(None, None, fn)._all_moments_variance_regression
+    extra = {}
+
+    def one_estimate():
+        # reset + push of every level + finalize: one call of the C ABI; with more than one rank the packed partial sums
+        # stay on the device and go through ONE all-reduce before the host reads them
+        n, n_rm, s, sp = acc.estimate(chunks)
+        _, _, mean, var = host_formulas(n, s, sp, level_stats)
+        if cfg["mode"] == "cov":
+            s_m, sp_m = moments_from_covariance(s, sp, R)
+            _, raw_vars = level_stats(n, s_m, sp_m)
+            reg_vars = regress(raw_vars, np.array(steps_h))
+            extra["n_estimated"] = [int(v) for v in estimate_n_samples_for_target_variance(1e-6, reg_vars, n_ops, n_levels=L)]
+        return n, n_rm, mean, var
+
+    elapsed, pre, res, kt = timed_loop(one_estimate, acc, steps, warmup, preroll_ms, ctx)
+    n, n_rm, mean, var = res
+    n_local = [int(data[l][0].shape[0]) for l in range(L)]
+    samples_per_step = int(ctx.sum_over_ranks([float(sum(n_local))])[0])      # whole job: every rank's shard
+    pairs, singles = sum(n_local[1:]), n_local[0]         # this rank's launches
+    out = {
+        "value": samples_per_step * R * steps / elapsed, "unit": "moment-evals/s", "steps": steps, "warmup": warmup,
+        "preroll_steps": pre, "ms_per_step": 1e3 * elapsed / steps,
+        "roofline": roofline_block(cfg["mode"], cfg.get("basis", "Legendre"), R, pairs, singles, kt, steps, config_key),
+        "result_check": {"mean0": float(np.ravel(mean)[0]), "var0": float(np.ravel(var)[0]), "n_removed": [int(v) for v in n_rm]},
+    }
+    out["result_check"].update(extra)
+    acc.close()
+    return out
+
+
+def exchange_block(fn, L, R, ctx, reps=50):
+    """The exchange step alone: `reps` all-reduces of a packed [2 L + 2 L R^2] fp64 buffer (what one sharded covariance
+    estimate sends), barrier + synchronize on both sides, max over ranks."""
+    from mlmc_amd.engine import allreduce_partials
+    torch = ctx.torch
+    on_gpu = ctx.dist.get_backend() == "nccl"
+    k = 2 * L + 2 * L * R * R
+    buf = torch.zeros(k, dtype=torch.float64, device=ctx.dev if on_gpu else "cpu")
+    for _ in range(5):
+        allreduce_partials(buf)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        allreduce_partials(buf)
+    ctx.sync()
+    ms = ctx.max_over_ranks([1e3 * (time.perf_counter() - t0) / reps])[0]
+    return {"collective": "all-reduce (sum) of the packed fp64 partials n | n_rm | s | sp", "backend": ctx.dist.get_backend(),
+            "bytes_per_rank": 8 * k, "allreduce_ms": round(ms, 4),
+            "note": "all-reduce + copy of the reduced sums to the host, timed alone; inside a step it follows the kernels on the same stream"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5, 6],
+                    help="default: 3 (BASELINE configs[2]) + secondary blocks at N = 1, configs[3] sharded at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1 default line without the secondary blocks")
     ap.add_argument("--preroll-ms", type=float, default=250.0,
                     help="untimed load before the W warm-up steps: the shader clock of an idle MI355X needs ~70 ms of "
                          "continuous work to reach its steady state (0 = none)")
@@ -118,173 +296,103 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node {}".format(args.gpus)
 
     from mlmc_amd import _lib, Legendre, Spline
-    from mlmc_amd.engine import LevelAccumulator, level_stats
+    from mlmc_amd.engine import shard_bounds
     from mlmc_amd.estimator import determine_level_parameters
 
     _lib.init(local_rank, _lib.FLAG_TIMING)
     dev = torch.device("cuda", local_rank)
-    cfg = CONFIGS[args.config]
-    L, n_l, R = cfg["L"], cfg["n_per_level"], cfg["R"]
-    if cfg["mode"] == "tree":
-        out = tree_bench(args, cfg, world, rank, dev, dist)
+    ctx = Ctx(world, rank, dev, dist, torch)
+
+    def finish(out):
+        if dist.is_initialized():
+            dist.barrier()
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         if rank == 0:
             print(json.dumps(out), flush=True)
         if dist.is_initialized():
             dist.destroy_process_group()
-        return
-    dom = (-3.7190164854556804, 3.7190164854556804)   # scipy.stats.norm().ppf([1e-4, 1 - 1e-4]) (test/test_run.py:71)
-    steps = [s[0] for s in determine_level_parameters(L, [0.5, 0.01])] if L > 1 else [0.01]
-    fn = Spline(R, dom) if cfg.get("basis") == "Spline" else Legendre(R, dom)
-    mode = LevelAccumulator.MOMENTS if cfg["mode"] == "moments" else LevelAccumulator.COV
-    acc = LevelAccumulator(fn, L, mode)
 
-    data = [synth_device(l, n_l, steps, 1234 + 1000 * rank, dev) for l in range(L)]
+    key = args.config
+    if key is None:
+        key = 3 if world == 1 else "sharded"
+    cfg = dict(CONFIGS[key])
+    if cfg["mode"] == "tree":
+        return finish(tree_bench(args, cfg, world, rank, dev, dist))
+    L, R = cfg["L"], cfg["R"]
+    if key == "sharded":
+        # MLMC_BENCH_TOTAL_PER_LEVEL: smaller totals for rehearsals on one GPU (tests); the default is BASELINE's 1e8
+        total = int(os.environ.get("MLMC_BENCH_TOTAL_PER_LEVEL", cfg["n_total_per_level"]))
+        lo, hi = shard_bounds(total, rank, world)
+        cfg["n_per_level"] = hi - lo
+        cfg["n_total_per_level"] = total
+    n_l = cfg["n_per_level"]
+    steps_h = [s[0] for s in determine_level_parameters(L, [0.5, 0.01])] if L > 1 else [0.01]
+    fn = Spline(R, DOMAIN) if cfg.get("basis") == "Spline" else Legendre(R, DOMAIN)
+    data = [synth_device(l, n_l, steps_h, 1234 + 1000 * rank, dev) for l in range(L)]
     torch.cuda.synchronize()
 
-    # configs[2] also re-allocates the samples per level: level variances of the moments (a second, cheap accumulation
-    # pass) -> log-quadratic regression over the levels -> n_samples for a target variance (estimator.py:56-74,366-385)
-    acc_mom = LevelAccumulator(fn, L, LevelAccumulator.MOMENTS) if cfg["mode"] == "cov" else None
-    n_ops = [(1.0 / h) ** 2 * np.log(max(1.0 / h, 2.0)) for h in steps]      # synth_simulation.py:133-134
-    from mlmc_amd.estimator import Estimate, estimate_n_samples_for_target_variance
-    regress = Estimate(None, None, fn)._all_moments_variance_regression
-    extra = {}
-
-    chunks = [(l, data[l][0], data[l][1]) for l in range(L)]
-
-    def one_estimate():
-        # reset + push of every level + finalize: one call of the C ABI; with more than one rank the packed partial sums
-        # stay on the device and go through ONE RCCL all-reduce before the host reads them
-        n, n_rm, s, sp = acc.estimate(chunks)
-        l_means, l_vars = level_stats(n, s, sp)
-        mean = np.sum(l_means, axis=0)
-        if n.min() > 0:
-            var = np.sum(l_vars / n[:, None], axis=0)
-        else:
-            with np.errstate(all="ignore"):
-                var = np.sum(l_vars / n[:, None], axis=0)
-        if acc_mom is not None:
-            acc_mom.reset()
-            for l in range(L):
-                acc_mom.push(l, data[l][0], data[l][1])
-            n2, _, s2, sp2 = acc_mom.finalize()
-            _, raw_vars = level_stats(n2, s2, sp2)
-            reg_vars = regress(raw_vars, np.array(steps))
-            extra["n_estimated"] = [int(v) for v in estimate_n_samples_for_target_variance(1e-6, reg_vars, n_ops, n_levels=L)]
-        return n, n_rm, mean, var
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    import gc
-    # no cyclic-GC pauses inside the timed region (a gen-2 collection of the torch-sized heap costs ~40 ms); collected
-    # before the warm-up so that the timed steps follow the warm-up without an idle gap (an idle GPU drops its clock)
-    gc.collect()
-    gc.disable()
-    preroll_steps = preroll(one_estimate, args.preroll_ms, world, dist, torch, dev)
-    for _ in range(args.warmup):
-        one_estimate()
-    # kernel-time bookkeeping of the timed region only
-    acc.kernel_time()                                # drop the warm-up launches from the totals
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = one_estimate()
-    sync()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    # HIP events around every launch of the dominant kernel in the timed region (config 3: the covariance kernel),
-    # recorded on the library's stream and read back once, after the clock has stopped
-    kt = list(acc.kernel_time())
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor(kt, dtype=torch.float64, device=dev)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kt = [float(k[0]), int(k[1]), int(k[2])]
-
-    n, n_rm, mean, var = res
-    samples_per_step = world * L * n_l
-    evals_per_step = samples_per_step * R
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = evals_per_step * args.steps / elapsed
-
-    # ---- roofline of the dominant kernel (HIP events on the library's stream) -------------------------
-    avg_launch_ms = kt[0] / max(kt[1], 1)
-    bytes_per_launch = kt[2] / max(kt[1], 1)
-    achieved_gbs = (kt[2] / 1e9) / (kt[0] / 1e3) if kt[0] > 0 else 0.0
-    # algorithmic flops, reference operation count: 14 R per pair, 8 R per level-0 sample;
-    # covariance adds 6 R^2 (three R x R x n contractions) per pair, 4 R^2 at level 0
-    pairs = (L - 1) * n_l
-    singles = n_l
-    if cfg["mode"] == "moments":
-        flops = (14 * R) * pairs + (8 * R) * singles
-        alu_peak, alu_bound, kname = FP64_VALU_PEAK_TFLOPS, "valu_f64", "k_moments_accum"
-    else:
-        flops = (14 * R + 6 * R * R) * pairs + (8 * R + 4 * R * R) * singles
-        alu_peak, alu_bound, kname = FP64_MFMA_PEAK_TFLOPS, "mfma_f64", "k_cov_accum"
-    step_kernel_s = (kt[0] / 1e3) / args.steps
-    achieved_tflops = flops / step_kernel_s / 1e12 if step_kernel_s > 0 else 0.0
-    traffic, traffic_src = pmc_traffic_per_launch(args.config, kname, n_l, L, kt[1] // max(args.steps, 1))
-    if cfg.get("basis") == "Spline":
-        kname = "k_spline_accum"     # sparse LDS-atomic kernel: <= 8 of the R sums touched per sample, no dense flop count applies
-    roofline = {
-        "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-        "kernel": kname, "avg_launch_ms": round(avg_launch_ms, 5), "alg_bytes_per_launch": int(bytes_per_launch),
-        "launches_per_step": kt[1] // max(args.steps, 1),
-        # the kernel is fp64-ALU bound for R >= 12: the binding roof, reported beside the HBM one
-        "alu": {"bound": alu_bound, "achieved": round(achieved_tflops, 3), "peak": alu_peak, "unit": "TFLOP/s",
-                "frac": round(achieved_tflops / alu_peak, 4), "alg_flops_per_step": int(flops)},
-    }
-
-    if cfg["mode"] != "moments":
-        # the covariance kernel is MFMA-bound (R = 64: > 1000 flop/B): the matrix-core roof is the top-level one,
-        # the HBM figures stay beside it
-        hbm = {k: roofline[k] for k in ("achieved", "peak", "unit", "frac")}
-        alu = roofline.pop("alu")
-        roofline.update({"bound": "mfma", "achieved": alu["achieved"], "peak": alu["peak"], "unit": alu["unit"],
-                         "frac": alu["frac"], "alg_flops_per_step": alu["alg_flops_per_step"], "hbm": hbm})
-    if cfg.get("basis") == "Spline":
-        roofline.pop("alu")
-        roofline["note"] = "ds_add_f64 (LDS atomic) bound: 8 updates per sample pair into per-wave copies of the 2 R sums"
+    head = estimate_block(cfg, data, fn, steps_h, ctx, args.steps, args.warmup, args.preroll_ms, key)
     out = {
-        "metric": "moment-evals/sec (samples x n_moments)", "value": value, "unit": "moment-evals/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll_steps, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "metric": "moment-evals/sec (samples x n_moments)", "value": head["value"], "unit": "moment-evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": head["preroll_steps"],
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if key == "sharded" else "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["workload"], "levels": L, "samples_per_level_per_gpu": n_l, "n_moments": R,
-                   "basis": cfg.get("basis", "Legendre"), "estimate": cfg["mode"], "exchange": "all-reduce of [L,(2+2K)] partial sums" if world > 1 else "none"},
-        "roofline": roofline,
-        "result_check": {"mean0": float(np.ravel(mean)[0]), "var0": float(np.ravel(var)[0]), "n_removed": [int(v) for v in n_rm]},
+                   "basis": cfg.get("basis", "Legendre"), "estimate": cfg["mode"],
+                   "exchange": "all-reduce of [L,(2+2K)] partial sums" if world > 1 else "none"},
+        "roofline": head["roofline"], "result_check": head["result_check"],
     }
-    out["result_check"].update(extra)
+    if key == "sharded":
+        out["config"]["samples_per_level_total"] = cfg["n_total_per_level"]
+    if dist.is_initialized() and cfg["mode"] == "cov":
+        out["exchange"] = exchange_block(fn, L, R, ctx)
 
+    # ---- secondary blocks of the default N = 1 line -----------------------------------------------------------------
+    if args.config is None and world == 1 and not args.no_secondary:
+        # the stand-alone mean + variance estimate on the same samples (R = 64): the fp64-VALU figure beside the MFMA one
+        mcfg = dict(cfg, mode="moments", workload="configs[2] samples, stand-alone Legendre n_moments=64 mean+var estimate")
+        blk = estimate_block(mcfg, data, fn, steps_h, ctx, 50, 10, 0.0, 3)
+        out["moments_r64"] = dict(blk, config={"workload": mcfg["workload"], "levels": L, "samples_per_level_per_gpu": n_l, "n_moments": R})
     # ---- max-entropy PDF solve time (second half of BASELINE's metric), outside the timed region, rank 0 ------------
     if rank == 0:
+        from mlmc_amd.engine import LevelAccumulator, level_stats
         out["pdf_solve"] = pdf_solve_timing(fn, L, data, LevelAccumulator, level_stats)
-
     # ---- CPU baseline + parity gate on a bounded sample (rank 0, N = 1 only) ---------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from mlmc_amd.engine import LevelAccumulator, level_stats
         from oracle import oracle_np as onp            # the checker: only this leg touches oracle/
-        out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_stats)
-    if dist.is_initialized():
-        dist.barrier()
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist.is_initialized():
-        dist.destroy_process_group()
+        out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(cfg, fn, DOMAIN, steps_h, onp, LevelAccumulator, level_stats)
+    if args.config is None and world == 1 and not args.no_secondary:
+        del data
+        torch.cuda.empty_cache()
+        for name, k2, st, wu in (("configs1", 2, 100, 20), ("north_star", "north_star", 3, 1)):
+            c2 = CONFIGS[k2]
+            sh = [s[0] for s in determine_level_parameters(c2["L"], [0.5, 0.01])]
+            f2 = Legendre(c2["R"], DOMAIN)
+            d2 = [synth_device(l, c2["n_per_level"], sh, 1234, dev) for l in range(c2["L"])]
+            torch.cuda.synchronize()
+            blk = estimate_block(c2, d2, f2, sh, ctx, st, wu, 100.0, 3 if k2 == "north_star" else k2)
+            blk["config"] = {"workload": c2["workload"], "levels": c2["L"], "samples_per_level_per_gpu": c2["n_per_level"],
+                             "n_moments": c2["R"], "estimate": c2["mode"]}
+            if k2 == "north_star":
+                # the north star names moments AND covariance: the stand-alone moments estimate of the same 1e8 samples
+                m2 = estimate_block(dict(c2, mode="moments"), d2, f2, sh, ctx, 20, 5, 0.0, 3)
+                blk["moments"] = {k: m2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "roofline")}
+                blk["both_ms"] = blk["ms_per_step"] + m2["ms_per_step"]
+                blk["hbm_frac_both"] = round((c2["L"] * 2 - 1) * c2["n_per_level"] * 8.0 * 2 / (blk["both_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
+                blk["note"] = ("north_star asks for >= 60 % of the HBM roofline on moments + covariance at R = 64; in fp64 the "
+                               "covariance is matrix-core bound (>= 1000 flop/B) and the moments pass VALU bound (56 flop/B): the "
+                               "binding roofs are reported, the HBM fraction of both passes is hbm_frac_both (SURVEY 8(d), fact 9)")
+            out[name] = blk
+            del d2
+            torch.cuda.empty_cache()
+    finish(out)
 
 
 def tree_bench(args, cfg, world, rank, dev, dist):
     """--config 6: a Quantity tree over two stored rows, lowered to a register program and evaluated by k_expr
     (mlmc_amd/csrc/expr.hip), feeding the moments estimate.  Step = evaluation of every level's chunk + one estimate."""
-    import gc
     import torch
     from mlmc_amd import Legendre
     from mlmc_amd.engine import LevelAccumulator, level_stats
@@ -294,6 +402,7 @@ def tree_bench(args, cfg, world, rank, dev, dist):
     from mlmc_amd.sample_storage import Memory
     from mlmc_amd.estimator import determine_level_parameters
     L, n_l, R = cfg["L"], cfg["n_per_level"], cfg["R"]
+    ctx = Ctx(world, rank, dev, dist, torch)
     steps = [s[0] for s in determine_level_parameters(L, [0.5, 0.01])]
     # the tree, built through the reference-style API over a (tiny) storage with the same two stored rows
     spec = [QuantitySpec(name="q", unit="", shape=(2, 1), times=[1], locations=['0'])]
@@ -326,41 +435,33 @@ def tree_bench(args, cfg, world, rank, dev, dist):
             keep.append((f, c))
             acc.push(l, f[0], None if c is None else c[0])
         n, n_rm, s, sp = acc.finalize()
-        l_means, l_vars = level_stats(n, s, sp)
-        with np.errstate(all="ignore"):
-            return n, n_rm, np.sum(l_means, axis=0), np.sum(l_vars / n[:, None], axis=0)
+        _, _, mean, var = host_formulas(n, s, sp, level_stats)
+        return n, n_rm, mean, var
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    plan.kernel_time()
+    steps_k, warm = args.steps, args.warmup
     gc.collect()
     gc.disable()
-    preroll_steps = preroll(one_step, args.preroll_ms, world, dist, torch, dev)
-    for _ in range(args.warmup):
+    preroll_steps = preroll(one_step, args.preroll_ms, ctx)
+    for _ in range(warm):
         one_step()
     plan.kernel_time()
     acc.kernel_time()
-    sync()
+    ctx.sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps_k):
         n, n_rm, mean, var = one_step()
-    sync()
-    elapsed = time.perf_counter() - t0
+    ctx.sync()
+    elapsed = ctx.max_over_ranks([time.perf_counter() - t0])[0]
     gc.enable()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     x_ms, x_launches, x_bytes = plan.kernel_time()
     a_ms, a_launches, _ = acc.kernel_time()
     gbs = (x_bytes / 1e9) / (x_ms / 1e3) if x_ms > 0 else 0.0
-    traffic, traffic_src = pmc_avg_bytes_per_dispatch(args.config, "k_expr")
+    traffic, traffic_src = pmc_avg_bytes_per_dispatch(6, "k_expr")
     out = {
-        "metric": "moment-evals/sec (samples x n_moments)", "value": world * L * n_l * R * args.steps / elapsed,
-        "unit": "moment-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll_steps,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "moment-evals/sec (samples x n_moments)", "value": world * L * n_l * R * steps_k / elapsed,
+        "unit": "moment-evals/s", "n_gpus": world, "steps": steps_k, "warmup": warm, "preroll_steps": preroll_steps,
+        "ms_per_step": 1e3 * elapsed / steps_k, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": cfg["workload"], "levels": L, "samples_per_level_per_gpu": n_l, "n_moments": R,
                    "tree": "(x - 0.1) * (x - 0.1) / (np.abs(y) + 1.0)", "program_instructions": len(plan.prog),
@@ -368,8 +469,8 @@ def tree_bench(args, cfg, world, rank, dev, dist):
         "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_expr",
                      "avg_launch_ms": round(x_ms / max(x_launches, 1), 5),
-                     "alg_bytes_per_launch": int(x_bytes / max(x_launches, 1)), "launches_per_step": x_launches // max(args.steps, 1),
-                     "moments_kernel_ms_per_step": round(a_ms / max(args.steps, 1), 5)},
+                     "alg_bytes_per_launch": int(x_bytes / max(x_launches, 1)), "launches_per_step": x_launches // max(steps_k, 1),
+                     "moments_kernel_ms_per_step": round(a_ms / max(steps_k, 1), 5)},
         "result_check": {"mean0": float(mean[0]), "var0": float(var[0]), "n_removed": [int(v) for v in n_rm]},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -436,67 +537,51 @@ def pdf_solve_timing(fn, L, data, LevelAccumulator, level_stats):
             "nit": int(res.nit), "grad_norm": float(res.fun_norm), "success": bool(res.success)}
 
 
-def pmc_traffic_per_launch(config, kname, n_l, L, launches_per_step):
-    """HBM bytes per accumulation launch from the most recent committed rocprofv3 PMC passes of this same command
-    (profiles/rNN_pmc_config<k>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs).  FETCH_SIZE is in KB and, on
-    gfx950, counts half of a coalesced streaming read (guide, HBM section) -> read bytes = 2 * FETCH_SIZE * 1024.
-    The profiles hold per-dispatch averages per kernel instantiation; they are summed over the dispatches that make one
-    launch-equivalent of this run (one multi-level launch = all levels).  None when no profile is committed."""
+def _latest_pmc(config_key):
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_config{}.json".format(config))))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_config{}.json".format(config_key))))
     if not files:
         return None, None
     with open(files[-1]) as f:
-        prof = json.load(f)
-    read_b = write_b = 0.0
-    n_disp = 0
-    for name, e in prof.items():
-        if kname not in name or "FETCH_SIZE_avg_per_dispatch" not in e:
-            continue
-        per_step = e.get("dispatches_fetch", 0)
-        read_b += 2.0 * e["FETCH_SIZE_avg_per_dispatch"] * 1024.0 * per_step
-        write_b += e.get("WRITE_SIZE_avg_per_dispatch", 0.0) * 1024.0 * per_step
-        n_disp += per_step
-    if n_disp == 0:
-        return None, None
-    # the profile run covered `steps_prof` estimates; normalise to one estimate, then to one launch of THIS run
-    levels_bytes = (2 * L - 1) * n_l * 8.0
-    steps_prof = max(1, round(read_b / levels_bytes))
-    per_step = (read_b + write_b) / steps_prof
-    return int(per_step / max(launches_per_step, 1)), os.path.basename(files[-1])
+        return json.load(f), os.path.basename(files[-1])
 
 
-def pmc_avg_bytes_per_dispatch(config, kname):
-    """Average HBM bytes per dispatch of the kernels matching `kname` from the committed PMC passes (same corrections as
-    pmc_traffic_per_launch)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_config{}.json".format(config))))
-    if not files:
+def pmc_traffic(config_key, kname, launches_per_step):
+    """HBM bytes per accumulation launch from the most recent COMMITTED rocprofv3 PMC passes of this command
+    (profiles/rNN_pmc_config<k>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; not measured in this run -- the file is
+    named in `traffic_source`).  FETCH_SIZE is in KB and, on gfx950, counts half of a coalesced streaming read (guide, HBM
+    section) -> read bytes = 2 * FETCH_SIZE * 1024.  The profiles hold per-dispatch averages per kernel instantiation;
+    the average over the dispatches of the matching kernels is returned.  None when no profile is committed."""
+    return pmc_avg_bytes_per_dispatch(config_key, kname)
+
+
+def pmc_avg_bytes_per_dispatch(config_key, kname):
+    prof, name = _latest_pmc(config_key)
+    if prof is None:
         return None, None
-    with open(files[-1]) as f:
-        prof = json.load(f)
     total = 0.0
     n_disp = 0
-    for name, e in prof.items():
-        if kname not in name or "FETCH_SIZE_avg_per_dispatch" not in e:
+    for kn, e in prof.items():
+        if kname not in kn or "FETCH_SIZE_avg_per_dispatch" not in e:
             continue
         d = e.get("dispatches_fetch", 0)
         total += (2.0 * e["FETCH_SIZE_avg_per_dispatch"] + e.get("WRITE_SIZE_avg_per_dispatch", 0.0)) * 1024.0 * d
         n_disp += d
     if n_disp == 0:
         return None, None
-    return int(total / n_disp), os.path.basename(files[-1])
+    return int(total / n_disp), name
 
 
 def cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_stats):
-    """NumPy restatement of the reference path (oracle, same operation order as the reference: legvander,
-    transpose, NaN mask, fine - coarse, two np.sum), single thread like the reference, streamed in chunks."""
+    """NumPy restatement of the reference path (oracle, same operation order as the reference: legvander, transpose,
+    NaN mask, fine - coarse, two np.sum; covariance: the reference's per-sample einsum outer products), single thread
+    like the reference, streamed in chunks; a bounded sample (about 10 s of CPU work)."""
     L, R = cfg["L"], cfg["R"]
     if cfg["mode"] == "moments":
-        n_s, chunk = 10_000_000, 250_000   # the full configs[1] size: about 10 s of NumPy on one core
+        n_s, chunk = 10_000_000 * 32 // max(R, 32), 250_000   # about 10 s of NumPy on one core
         rows = onp.moments_rows
     else:
-        n_s, chunk = 6_000, 1_000       # the reference form materialises [2, n, R, R] per chunk
+        n_s, chunk = 60_000 * (64 * 64) // (R * R), 1_000     # the reference form materialises [2, n, R, R] per chunk
         rows = onp.covariance_rows
     b = onp.Basis(onp.SPLINE if cfg.get("basis") == "Spline" else onp.LEGENDRE, R, dom)
     if cfg.get("basis") == "Spline":
@@ -520,7 +605,7 @@ def cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_st
     acc = LevelAccumulator(fn, L, mode)
     for l, (f, c) in enumerate(host):
         acc.push(l, f, c)
-    n, n_rm, s, sp = acc.finalize()
+    n, n_rm, s, sp = acc.finalize(reduce=False)
     l_means, l_vars = level_stats(n, s, sp)
     rms = np.sqrt(np.abs(ref.sums_sq) / np.maximum(ref.n_samples[:, None], 1))
     err_mean = float(np.max(np.abs(l_means - ref.l_means) / np.maximum(np.abs(ref.l_means), rms + 1e-300)))

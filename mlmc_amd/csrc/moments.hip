@@ -10,6 +10,7 @@
 // recurrences for fine and coarse kept in registers, per-lane fp64 accumulators for sum(d) and sum(d^2),
 // wave shuffles + LDS for the block partial, and a fixed-order second kernel for the grid reduction
 // (bitwise reproducible run to run).
+#include <cstdlib>
 #include <cstring>
 
 #include "device_basis.hpp"
@@ -385,6 +386,165 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// 48 < R <= 64 in ONE pass over the samples at two waves per SIMD (Legendre, monomials).
+// A 64-term register tile needs 256 accumulator VGPRs (one wave per SIMD, and a lone wave cannot fill the fp64 pipe); two
+// 32-term passes re-run the first 32 recurrence steps in the second pass (+29 % instructions).  Here the four waves of a
+// workgroup split the TERMS of the same samples: waves 0-1 ("head") own terms [0, 32) -- loads, transform, keep
+// flags, counts, recurrence steps 0..31 -- and hand the state of every recurrence (x, Q_31, Q_30; masked samples: zeros)
+// to waves 2-3 ("tail") through a double-buffered LDS image; the tail continues the same recurrences through terms
+// [32, 64) of the previous trip's samples while the head works on the next trip.  One workgroup barrier per trip (two
+// samples per head lane).  Every recurrence step runs exactly once: the instruction count is that of a single
+// 64-term pass, the occupancy that of the 32-term tile.  Partial rows [2][64] as a 64-term tile would write them.
+// ------------------------------------------------------------------------------------------
+constexpr int SPLIT_LANES = 128;                 // sample lanes per workgroup (head lanes = tail lanes)
+constexpr int SPLIT_HALF = 32;                   // terms per half
+
+template <int KIND>
+__device__ __forceinline__ void split_export(const TermGen<KIND> &g, double *__restrict__ slot) {
+    slot[0 * SPLIT_LANES] = g.x;
+    slot[1 * SPLIT_LANES] = g.p1;
+    if (KIND == MLMC_LEGENDRE) slot[2 * SPLIT_LANES] = g.p2;
+}
+template <int KIND>
+__device__ __forceinline__ void split_import(TermGen<KIND> &g, const double *__restrict__ slot) {
+    g.x = slot[0 * SPLIT_LANES];
+    g.p1 = slot[1 * SPLIT_LANES];
+    g.p2 = KIND == MLMC_LEGENDRE ? slot[2 * SPLIT_LANES] : 0.0;
+    g.c1 = g.s1 = 0.0;
+}
+
+template <int KIND, bool PAIR, bool PLAIN>
+__device__ __forceinline__ void split_head(const BasisParams &bp, const double *__restrict__ fine, const double *__restrict__ coarse,
+                                           const uint8_t *__restrict__ mask, int64_t n, int bid, int nb, int n_trips,
+                                           double *__restrict__ hand, double (&s)[SPLIT_HALF], double (&sp)[SPLIT_HALF],
+                                           int &n_keep, int &n_rm) {
+    const int64_t T = (int64_t)nb * SPLIT_LANES;
+    const int l128 = threadIdx.x & (SPLIT_LANES - 1);
+    int64_t i0 = (int64_t)bid * SPLIT_LANES + l128, i1 = i0 + T;
+    double f0 = 0, f1 = 0, c0 = 0, c1 = 0;
+    uint8_t m0 = 1, m1 = 1;
+    if (i0 < n) { f0 = fine[i0]; if (PAIR) c0 = coarse[i0]; if (!PLAIN && mask) m0 = mask[i0]; }
+    if (i1 < n) { f1 = fine[i1]; if (PAIR) c1 = coarse[i1]; if (!PLAIN && mask) m1 = mask[i1]; }
+    for (int k = 0; k < n_trips; ++k) {
+        const bool v0 = i0 < n, v1 = i1 < n;
+        const double xf0 = f0, xf1 = f1, xc0 = c0, xc1 = c1;
+        const uint8_t mm0 = m0, mm1 = m1;
+        const int64_t j0 = i0 + 2 * T, j1 = i1 + 2 * T;      // next trip's loads first
+        if (j0 < n) { f0 = fine[j0]; if (PAIR) c0 = coarse[j0]; if (!PLAIN && mask) m0 = mask[j0]; }
+        if (j1 < n) { f1 = fine[j1]; if (PAIR) c1 = coarse[j1]; if (!PLAIN && mask) m1 = mask[j1]; }
+        bool kf0, kf1, kc0 = true, kc1 = true;
+        const double tf0 = PLAIN ? transform_plain(bp, xf0, kf0) : transform_value(bp, xf0, kf0);
+        const double tf1 = PLAIN ? transform_plain(bp, xf1, kf1) : transform_value(bp, xf1, kf1);
+        double tc0 = 0, tc1 = 0;
+        if (PAIR) {
+            tc0 = PLAIN ? transform_plain(bp, xc0, kc0) : transform_value(bp, xc0, kc0);
+            tc1 = PLAIN ? transform_plain(bp, xc1, kc1) : transform_value(bp, xc1, kc1);
+        }
+        const bool k0 = v0 && kf0 && kc0 && (PLAIN || mm0 != 0);
+        const bool k1 = v1 && kf1 && kc1 && (PLAIN || mm1 != 0);
+        n_keep += (int)k0 + (int)k1;
+        n_rm += (int)(v0 && !k0) + (int)(v1 && !k1);
+        const double w0 = k0 ? 1.0 : 0.0, w1 = k1 ? 1.0 : 0.0;
+        TermGen<KIND> gf0, gf1, gc0, gc1;
+        gf0.init(k0 ? tf0 : 0.0, w0, bp);
+        gf1.init(k1 ? tf1 : 0.0, w1, bp);
+        if (PAIR) { gc0.init(k0 ? tc0 : 0.0, w0, bp); gc1.init(k1 ? tc1 : 0.0, w1, bp); }
+#pragma unroll
+        for (int i = 0; i < SPLIT_HALF; ++i) {
+            double d0 = gf0.next(i);
+            double d1 = gf1.next(i);
+            if (PAIR) { d0 -= gc0.next(i); d1 -= gc1.next(i); }
+            s[i] += d0;
+            sp[i] = __builtin_fma(d0, d0, sp[i]);
+            s[i] += d1;
+            sp[i] = __builtin_fma(d1, d1, sp[i]);
+        }
+        double *__restrict__ slot = hand + (size_t)(k & 1) * (12 * SPLIT_LANES) + l128;
+        split_export<KIND>(gf0, slot);
+        split_export<KIND>(gf1, slot + 3 * SPLIT_LANES);
+        if (PAIR) { split_export<KIND>(gc0, slot + 6 * SPLIT_LANES); split_export<KIND>(gc1, slot + 9 * SPLIT_LANES); }
+        __syncthreads();
+        i0 = j0;
+        i1 = j1;
+    }
+    __syncthreads();      // the tail's last trip
+}
+
+template <int KIND, bool PAIR>
+__device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, const double *__restrict__ hand,
+                                           double (&s)[SPLIT_HALF], double (&sp)[SPLIT_HALF]) {
+    const int l128 = threadIdx.x & (SPLIT_LANES - 1);
+    __syncthreads();      // the head's first trip
+    for (int k = 0; k < n_trips; ++k) {
+        const double *__restrict__ slot = hand + (size_t)(k & 1) * (12 * SPLIT_LANES) + l128;
+        TermGen<KIND> gf0, gf1, gc0, gc1;
+        split_import<KIND>(gf0, slot);
+        split_import<KIND>(gf1, slot + 3 * SPLIT_LANES);
+        if (PAIR) { split_import<KIND>(gc0, slot + 6 * SPLIT_LANES); split_import<KIND>(gc1, slot + 9 * SPLIT_LANES); }
+#pragma unroll
+        for (int i = 0; i < SPLIT_HALF; ++i) {
+            double d0 = gf0.next(SPLIT_HALF + i);
+            double d1 = gf1.next(SPLIT_HALF + i);
+            if (PAIR) { d0 -= gc0.next(SPLIT_HALF + i); d1 -= gc1.next(SPLIT_HALF + i); }
+            s[i] += d0;
+            sp[i] = __builtin_fma(d0, d0, sp[i]);
+            s[i] += d1;
+            sp[i] = __builtin_fma(d1, d1, sp[i]);
+        }
+        __syncthreads();
+    }
+}
+
+template <int KIND, bool PLAIN>
+__global__ __launch_bounds__(ACC_THREADS, 2) void k_moments_accum_split(BasisParams bp, SegTable tab,
+                                                                        double *__restrict__ partials,
+                                                                        int64_t *__restrict__ pcounts) {
+    __shared__ double hand[2 * 12 * SPLIT_LANES];      // [buffer][recurrence (f0, f1, c0, c1) x (x, Q_31, Q_30)][lane]
+    __shared__ double wsum[4][2 * SPLIT_HALF];
+    __shared__ int ldc[2][2];
+    Seg sg = tab.seg[0];
+#pragma unroll
+    for (int k = 1; k < MAX_SEG; ++k)
+        if (k < tab.nseg && (int)blockIdx.x >= tab.seg[k].block0) sg = tab.seg[k];
+    const int bid = (int)blockIdx.x - sg.block0;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // trips of this workgroup (uniform): lane 0 of trip k starts at sample bid * 128 + k * 2 T
+    const int64_t T2 = 2 * (int64_t)sg.nblocks * SPLIT_LANES;
+    const int64_t first = (int64_t)bid * SPLIT_LANES;
+    const int n_trips = first < sg.n ? (int)((sg.n - first + T2 - 1) / T2) : 0;
+
+    double s[SPLIT_HALF], sp[SPLIT_HALF];
+#pragma unroll
+    for (int i = 0; i < SPLIT_HALF; ++i) { s[i] = 0.0; sp[i] = 0.0; }
+    int n_keep = 0, n_rm = 0;
+    if (wave < 2) {
+        if (sg.coarse) split_head<KIND, true, PLAIN>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
+        else split_head<KIND, false, PLAIN>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
+    } else {
+        if (sg.coarse) split_tail<KIND, true>(bp, n_trips, hand, s, sp);
+        else split_tail<KIND, false>(bp, n_trips, hand, s, sp);
+    }
+    // ---- block partial: butterfly sums inside every wave (fixed order), then head pair / tail pair added in fixed order ----
+#pragma unroll
+    for (int i = 0; i < SPLIT_HALF; ++i) {
+        const double a = wave_sum(s[i]), b = wave_sum(sp[i]);
+        if (lane == 0) { wsum[wave][i] = a; wsum[wave][SPLIT_HALF + i] = b; }
+    }
+    n_keep = wave_sum_i(n_keep);
+    n_rm = wave_sum_i(n_rm);
+    if (lane == 0 && wave < 2) { ldc[wave][0] = n_keep; ldc[wave][1] = n_rm; }
+    __syncthreads();
+    if (threadIdx.x < 4 * SPLIT_HALF) {
+        const int which = threadIdx.x / (2 * SPLIT_HALF), term = threadIdx.x % (2 * SPLIT_HALF);
+        const int half = term / SPLIT_HALF, i = term % SPLIT_HALF;
+        partials[(int64_t)blockIdx.x * (4 * SPLIT_HALF) + threadIdx.x] =
+            wsum[2 * half][which * SPLIT_HALF + i] + wsum[2 * half + 1][which * SPLIT_HALF + i];
+    }
+    if (threadIdx.x < 2) pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = ldc[0][threadIdx.x] + ldc[1][threadIdx.x];
+}
+
 // Grid reduction of one accumulation launch: block k (1024 threads) sums the partial rows of segment k in a fixed
 // order (bitwise reproducible): totals[which][t0 + i] += sum_b partials[b][which * RT + i], counts += sum_b pcounts[b].
 // 16 row groups x 64 columns, every thread keeps its <= 32 row loads in flight.  (Measured alternative: letting the
@@ -628,6 +788,26 @@ static int accum_dispatch(int op, bool plain, const BasisParams &bp, int rt_sel,
 #undef MLMC_RT_GO1
 }
 
+// term-split kernel (48 < R <= 64): op 0: *out = resident blocks per CU; op 1: launch
+template <int KIND, bool PLAIN>
+static int split_go(int op, const BasisParams &bp, const SegTable *tab, int total_blocks, double *partials, int64_t *pcounts, int *out) {
+    if (op == 0) {
+        MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(out, (const void *)k_moments_accum_split<KIND, PLAIN>, ACC_THREADS, 0));
+        return 0;
+    }
+    hipLaunchKernelGGL((k_moments_accum_split<KIND, PLAIN>), dim3(total_blocks), dim3(ACC_THREADS), 0, rt().stream, bp, *tab, partials, pcounts);
+    MLMC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+static int split_dispatch(int op, bool plain, const BasisParams &bp, const SegTable *tab, int total_blocks, double *partials,
+                          int64_t *pcounts, int *out) {
+    if (bp.kind == MLMC_LEGENDRE)
+        return plain ? split_go<MLMC_LEGENDRE, true>(op, bp, tab, total_blocks, partials, pcounts, out)
+                     : split_go<MLMC_LEGENDRE, false>(op, bp, tab, total_blocks, partials, pcounts, out);
+    return plain ? split_go<MLMC_MONOMIAL, true>(op, bp, tab, total_blocks, partials, pcounts, out)
+                 : split_go<MLMC_MONOMIAL, false>(op, bp, tab, total_blocks, partials, pcounts, out);
+}
+
 // Launch the pending segments of `a` (all passes over the terms), then the grid reduction.
 int flush_moments(mlmc_accum *a) {
     const int nseg = (int)a->pending.size();
@@ -638,19 +818,29 @@ int flush_moments(mlmc_accum *a) {
     const bool sparse_spline = bp.kind == MLMC_SPLINE;
     if (sparse_spline && R > SPLINE_MAX_R) return fail("spline moments: at most 512 basis functions");
     // Terms per pass.  A 64-term tile needs 256 accumulator VGPRs = one wave per SIMD, and a lone wave issues at 6.1
-    // cycles per instruction against 4.4-4.7 for two: polynomial bases with 48 < R <= 64 run as two 32-term passes at two
-    // waves per SIMD (the second pass re-runs the first 32 recurrence steps without accumulating: +29 % instructions,
-    // -15 % time; Fourier, whose second pass would repeat the sincos, measured slower that way and keeps one pass).
+    // cycles per instruction against 4.4-4.7 for two.  Polynomial bases with 48 < R <= 64 therefore run the term-split
+    // kernel (k_moments_accum_split: one pass, two waves per SIMD, every recurrence step once); MLMC_HIP_NO_SPLIT=1 keeps
+    // the earlier form -- two 32-term passes, the second re-running 32 recurrence steps without accumulating (+29 %
+    // instructions) -- for A/B runs.  Fourier, whose second pass would repeat the sincos, keeps one 64-term pass.
     // R <= 48 is one pass at two waves per SIMD; R > 64 uses 64-term passes.
-    const int pass_terms = (bp.kind != MLMC_FOURIER && R > 48 && R <= 64) ? 32 : MAX_TERMS_PER_PASS;
+    static const bool no_split = std::getenv("MLMC_HIP_NO_SPLIT") != nullptr;
+    const bool poly64 = (bp.kind == MLMC_LEGENDRE || bp.kind == MLMC_MONOMIAL) && R > 48 && R <= 64;
+    const bool split = poly64 && !no_split;
+    const int pass_terms = (poly64 && !split) ? 32 : MAX_TERMS_PER_PASS;
     for (int t0 = 0; t0 < (sparse_spline ? 1 : R); t0 += pass_terms) {
         const int n_terms = (R - t0 < pass_terms) ? R - t0 : pass_terms;
-        const int rt_sel = sparse_spline ? R : pick_rt(bp.kind, n_terms, t0);
+        const int rt_sel = sparse_spline ? R : (split ? 2 * SPLIT_HALF : pick_rt(bp.kind, n_terms, t0));
         const int width = 2 * rt_sel;
         int per_cu = 4;
         bool plain = bp.kind != MLMC_IDENTITY && !bp.is_log && bp.is_clip;
         for (const PendingSeg &p : a->pending) plain = plain && p.mask == nullptr;
-        if (!sparse_spline) {
+        if (split) {
+            static int occ_split[2][2];   // [Legendre | monomial][plain]; 0 = not asked yet
+            int &cached = occ_split[bp.kind == MLMC_LEGENDRE ? 0 : 1][plain ? 1 : 0];
+            if (cached == 0)
+                if (int rc = split_dispatch(0, plain, bp, nullptr, 0, nullptr, nullptr, &cached)) return rc;
+            per_cu = cached;
+        } else if (!sparse_spline) {
             static int occ_cache[8][4][2][65];   // resident blocks per CU of (kind, pass class, plain, RT); 0 = not asked yet
             int &cached = occ_cache[bp.kind & 7][t0 == 0 ? 0 : (t0 == 64 ? 1 : (t0 == 32 ? 2 : 3))][plain ? 1 : 0][rt_sel];
             if (cached == 0)
@@ -677,7 +867,8 @@ int flush_moments(mlmc_accum *a) {
             const PendingSeg &p = a->pending[k];
             // floor: the whole grid must be resident at once (one block over the limit would run as a second round)
             int nb = (int)((double)resident * ((double)p.n * (p.coarse ? W_PAIR : W_SINGLE)) / wsum);
-            const int64_t want = (p.n + 2 * ACC_THREADS - 1) / (2 * ACC_THREADS);
+            const int64_t per_trip = 2 * (split ? SPLIT_LANES : ACC_THREADS);      // samples a workgroup takes per trip
+            const int64_t want = (p.n + per_trip - 1) / per_trip;
             if (nb > want) nb = (int)want;
             if (nb < 1) nb = 1;
             tab.seg[k].fine = p.fine;
@@ -712,6 +903,8 @@ int flush_moments(mlmc_accum *a) {
             const size_t lds = sizeof(double) * 4 * 2 * (size_t)(R + 8);
             hipLaunchKernelGGL(k_spline_accum, dim3(total), dim3(ACC_THREADS), lds, st, bp, tab, R, a->d_partials, a->d_pcounts);
             MLMC_HIP_CHECK(hipGetLastError());
+        } else if (split) {
+            if (int rc = split_dispatch(1, plain, bp, &tab, total, a->d_partials, a->d_pcounts, nullptr)) return rc;
         } else if (int rc = accum_dispatch(1, plain, bp, rt_sel, &tab, total, t0, a->d_partials, a->d_pcounts, nullptr)) {
             return rc;
         }

@@ -238,6 +238,19 @@ def level_stats(n, s, sp):
     return l_means, l_vars
 
 
+def moments_from_covariance(s, sp, size, n_comp=1):
+    """Level sums of the moments read out of the level sums of their covariance: s / sp [L, n_comp * size * size] (rows
+    m * size^2 + i * size + j, the cov_at_bottom layout of mlmc_accum_finalize) -> (s_mom, sp_mom) [L, n_comp * size].
+    Row i = 0 of the per-sample outer products (quantity_estimate.py:131-147) is phi_0 phi_j with phi_0 = 1 for every
+    moment family of mlmc/moments.py, so  sum_n (f_0 f_j - c_0 c_j) = sum_n d_j  and  sum_n (f_0 f_j - c_0 c_j)^2 =
+    sum_n d_j^2: an estimate that has the covariance accumulators of a (quantity, moments_fn) pair needs no second pass
+    over the samples for the level means / variances of the moments (estimator.py:56-85)."""
+    L = s.shape[0]
+    s3 = np.asarray(s).reshape(L, n_comp, size, size)
+    sp3 = np.asarray(sp).reshape(L, n_comp, size, size)
+    return s3[:, :, 0, :].reshape(L, n_comp * size).copy(), sp3[:, :, 0, :].reshape(L, n_comp * size).copy()
+
+
 def percentiles(values, q_percent, nan_policy="omit"):
     """np.percentile(values[~isnan(values)], q_percent) evaluated on the device (radix select), bit-identical to NumPy's
     "linear" method.  values: NumPy array or torch CUDA tensor (flattened).

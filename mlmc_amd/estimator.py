@@ -44,13 +44,44 @@ class Estimate:
         if moments_fn is None:
             moments_fn = self._moments_fn
         r = qe.estimate_mean(qe.covariance(self._quantity, moments_fn))
+        self._cov_memo = (self._memo_key(moments_fn), r, moments_fn)
         return r.mean, r.var
 
+    def _memo_key(self, moments_fn):
+        """What a kept covariance estimate is valid for: this quantity object, these moment functions, the stamps of the
+        storage's levels (samples collected + modification counts, quantity_estimate._level_stamps)."""
+        try:
+            stamps = qe._level_stamps(self._quantity.get_quantity_storage())
+        except Exception:
+            return None
+        return (id(self._quantity), id(moments_fn), stamps, qe.device_cache_generation())
+
+    def _diff_vars_from_covariance(self, moments_fn):
+        """Level sums of the moments out of the last covariance estimate of the same (quantity, moments_fn, samples):
+        row 0 of the covariance rows is phi_0 phi_j = phi_j, so its level means / variances ARE those of the moments
+        (engine.moments_from_covariance) -- no second pass over the samples.  None when no such estimate is at hand."""
+        memo = getattr(self, "_cov_memo", None)
+        if memo is None or memo[0] is None or memo[0] != self._memo_key(moments_fn) or memo[2] is not moments_fn:
+            return None
+        from .moments import TransformedMoments
+        if isinstance(moments_fn, TransformedMoments):          # the first transformed moment need not be the constant
+            return None
+        r, size = memo[1], moments_fn.size
+        n_levels = r._l_means.shape[0]
+        n_comp = r._l_means.shape[1] // (size * size)
+        l_means, l_vars = engine.moments_from_covariance(r._l_means, r._l_vars, size, n_comp=n_comp)
+        from .quantity.quantity import QuantityMean
+        return QuantityMean(qe.moments(self._quantity, moments_fn).qtype, l_means=l_means.reshape(n_levels, -1),
+                            l_vars=l_vars.reshape(n_levels, -1), n_samples=r.n_samples, n_rm_samples=r.n_rm_samples)
+
     def estimate_diff_vars(self, moments_fn=None):
-        """-> (variances of the level differences [L, R], n_samples [L]) (reference: :76-85)."""
+        """-> (variances of the level differences [L, R], n_samples [L]) (reference: :76-85).  After estimate_covariance
+        of the same moment functions on unchanged samples the variances are read from the covariance estimate."""
         if moments_fn is None:
             moments_fn = self._moments_fn
-        r = qe.estimate_mean(qe.moments(self._quantity, moments_fn))
+        r = self._diff_vars_from_covariance(moments_fn)
+        if r is None:
+            r = qe.estimate_mean(qe.moments(self._quantity, moments_fn))
         return r.l_vars, r.n_samples
 
     def estimate_diff_vars_regression(self, n_created_samples, moments_fn=None, raw_vars=None):

@@ -88,8 +88,9 @@ class _DeviceChunkCache:
     the two passes of construct_density); the first pass uploads each chunk once, later passes -- and later estimates of
     the same quantity -- read it from HBM, where a whole multi-level estimate is one kernel launch.  288 GB of HBM3E
     hold 1.8e10 sample pairs; the default budget is MLMC_HIP_DEVICE_CACHE_GB = 64.
-    Keyed by (source quantity, level, chunk id, chunk slice, samples collected on the level): storages are append-only,
-    so a level that has grown misses and is uploaded again.  `device_cache_clear()` drops everything."""
+    Keyed by (source quantity, level, chunk id, chunk slice, stamp of the level = samples collected + the storage's
+    modification count where it keeps one, _level_stamps): storages are append-only, so a level that has grown misses and
+    is uploaded again.  `device_cache_clear()` drops everything."""
 
     def __init__(self):
         self._items = collections.OrderedDict()
@@ -163,8 +164,19 @@ def _lib_device():
 _device_cache = _DeviceChunkCache()
 
 
+_cache_generation = 0
+
+
+def device_cache_generation():
+    """Counts device_cache_clear() calls: results derived from resident samples (Estimate's kept covariance sums) are
+    valid for one generation."""
+    return _cache_generation
+
+
 def device_cache_clear():
     """Drop the HBM-resident sample chunks (call after modifying stored samples in place)."""
+    global _cache_generation
+    _cache_generation += 1
     _device_cache.clear()
 
 
@@ -327,6 +339,15 @@ def _cache_ident(source, plan):
     return id(source)
 
 
+def _level_stamps(storage_q):
+    """Per level (samples collected, storage version): what the resident rows of a level are valid for.  Storages of the
+    reference are append-only, so the count alone identifies a level's contents; mlmc_amd's own Memory storage also counts
+    its modifications per level (`_level_versions`), which covers a level that was rebuilt with the same number of samples.  Arrays of a
+    foreign storage edited in place are invisible to both: call device_cache_clear() after such an edit."""
+    versions = getattr(getattr(storage_q, "_storage", None), "_level_versions", None) or {}
+    return tuple((int(c), versions.get(level)) for level, c in enumerate(storage_q.n_collected()))
+
+
 def _chunk_key(ident, chunk_spec, n_collected):
     sl = chunk_spec.chunk_slice
     return (ident, chunk_spec.level_id, chunk_spec.chunk_id, None if sl is None else (sl.start, sl.stop),
@@ -390,7 +411,7 @@ def fine_samples_for_device(quantity, chunk_spec):
         return np.squeeze(quantity.samples(chunk_spec)[..., 0])
     storage_q = quantity.get_quantity_storage()
     try:
-        n_collected = tuple(storage_q.n_collected())
+        n_collected = _level_stamps(storage_q)
     except Exception:
         n_collected = None
     use_cache = _DeviceChunkCache.budget() > 0 and n_collected is not None
@@ -462,7 +483,7 @@ def estimate_mean(quantity, group=None, variance=True):
     n_comp = None
     use_cache = _DeviceChunkCache.budget() > 0 and not getattr(source, "_volatile", False)
     try:
-        n_collected = tuple(storage_q.n_collected())
+        n_collected = _level_stamps(storage_q)
     except Exception:
         n_collected = None
         use_cache = False

@@ -122,6 +122,9 @@ class Memory(SampleStorage):
                                                                           self._n_finished.get(level_id, 0) + len(block))])
 
     def _append(self, level_id, block, sample_ids):
+        # per-level modification count: stamp of the HBM-resident copies of the level (quantity_estimate._level_stamps)
+        self._level_versions = getattr(self, "_level_versions", {})
+        self._level_versions[int(level_id)] = self._level_versions.get(int(level_id), 0) + 1
         self._successful_sample_ids.setdefault(level_id, []).extend(sample_ids)
         self._n_finished[level_id] = self._n_finished.get(level_id, 0) + block.shape[0]
         if level_id in self._results:

@@ -152,6 +152,57 @@ def test_covariance_regression_allocation(hip):
     assert determine_n_samples(4, [1000, 10]).tolist() == g4["determine_n_samples_4_1000_10"]
 
 
+def test_level_variances_read_from_the_covariance_estimate(hip):
+    """estimate_covariance keeps its level sums; a following estimate_diff_vars(_regression) of the same moment functions on
+    unchanged samples takes the moments' level variances from row 0 of those sums (phi_0 = 1) instead of running a
+    second pass -- same values (<= 1e-10), same allocation as the golden G4, and a changed storage is noticed."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate, estimate_n_samples_for_target_variance
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    g2 = np.load(os.path.join(GOLDEN, "G2_estimate_mean.npz"))
+    with open(os.path.join(GOLDEN, "G4_alloc.json")) as f:
+        g4 = json.load(f)
+    dom = tuple(g2["domain"])
+    N, steps = g2["L5_N"], g2["L5_steps"]
+    levels = level_arrays(N, steps, 1, 0)
+    st = _storage(levels, steps, _scalar_spec())
+    q = make_root_quantity(st, _scalar_spec())['q'][1]['0'][0, 0]
+    fn = Legendre(32, dom)
+    ref_vars, ref_n = Estimate(q, st, fn).estimate_diff_vars(fn)              # the moments pass
+    est = Estimate(q, st, fn)
+    est.estimate_covariance()
+    assert est._diff_vars_from_covariance(fn) is not None
+    calls = []
+    orig = qe.estimate_mean
+    qe.estimate_mean = lambda *a, **k: calls.append(a) or orig(*a, **k)
+    try:
+        l_vars, n = est.estimate_diff_vars(fn)
+        reg_vars, n_ops = est.estimate_diff_vars_regression(list(N), fn)
+    finally:
+        qe.estimate_mean = orig
+    assert not calls                                                           # no pass over the samples
+    assert l_vars.shape == ref_vars.shape and np.array_equal(n, ref_n)
+    assert close(l_vars, ref_vars, None, 1e-10)
+    d = g4["L5_R32"]
+    assert close(reg_vars, np.array(d["reg_vars"]), None, 1e-9)
+    assert np.array_equal(estimate_n_samples_for_target_variance(1e-6, reg_vars, n_ops, n_levels=len(N)), d["n_estimated"])
+    # other moment functions, or samples that changed since, do not match the kept estimate
+    assert est._diff_vars_from_covariance(Legendre(32, dom)) is None
+    st.set_level_samples(4, levels[4][0].T[:10], levels[4][1].T[:10])
+    assert est._diff_vars_from_covariance(fn) is None
+    # a vector quantity: rows m R^2 + j of the covariance -> rows m R + j of the moments
+    lv = level_arrays([4000, 2500, 900], g2["L3_steps"], 4, 0)
+    stv = _storage(lv, g2["L3_steps"], _vec_spec())
+    qv = make_root_quantity(stv, _vec_spec())['q']
+    fn8 = Legendre(8, dom)
+    want, _ = Estimate(qv, stv, fn8).estimate_diff_vars(fn8)
+    ev = Estimate(qv, stv, fn8)
+    ev.estimate_covariance()
+    got, _ = ev.estimate_diff_vars(fn8)
+    assert ev._diff_vars_from_covariance(fn8) is not None and got.shape == want.shape and close(got, want, None, 1e-10)
+
+
 def test_orthogonal_moments_and_maxent(hip):
     from mlmc_amd import Legendre
     from mlmc_amd.tool import simple_distribution as sd

@@ -217,7 +217,7 @@ def test_reference_golden_chain(hip):
     assert close(means, g7["means"], 1.0, TOL) and close(vars_, g7["vars"], None, 1e-9)
 
 
-@pytest.mark.parametrize("R", [1, 3, 17, 48, 65, 100, 130])
+@pytest.mark.parametrize("R", [1, 3, 17, 48, 49, 56, 64, 65, 100, 130])
 def test_moment_counts_and_multi_pass(hip, R):
     """ragged sizes, every register-tile instantiation, and R > 64 (several passes over the terms)"""
     from mlmc_amd import Legendre
@@ -230,6 +230,75 @@ def test_moment_counts_and_multi_pass(hip, R):
     ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(b, x))
     _check_against(n, n_rm, s, sp, ref)
     assert s[0, 0] == float(n[0])                     # P0 sums are exact counts
+
+
+def test_term_split_kernel_for_49_to_64_moments(hip):
+    """48 < R <= 64 of a polynomial family runs k_moments_accum_split (waves 0-1: terms 0..31, waves 2-3: terms 32..63 of the
+    same samples, recurrence state handed over through LDS): ragged and tiny sizes (fewer samples than a workgroup has
+    lanes, one trip, many trips), level 0 only, host and device inputs, monomials, a vector quantity (mask kernel: the
+    general loop), log transform -- against the oracle, and against the two-pass form of the same library (child process
+    with MLMC_HIP_NO_SPLIT=1) to 1e-13."""
+    import subprocess
+    import sys
+    import torch
+    from mlmc_amd import Legendre, Monomial
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-3.7, 3.7)
+    steps = [0.5, 0.1, 0.03, 0.01]
+    for N in ([1], [127, 1], [128, 129, 255], [257, 1000, 5], [70001, 40099, 513, 2]):
+        levels = level_arrays(N, steps[:len(N)], 1, 5 if max(N) > 50 else 0)
+        for R in (49, 60, 64):
+            b = onp.Basis(onp.LEGENDRE, R, dom)
+            ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(b, x))
+            n, n_rm, s, sp = _run_accum(Legendre(R, dom), levels)
+            _check_against(n, n_rm, s, sp, ref)
+            assert s[0, 0] == float(n[0]) and not s[1:, 0].any()
+            # device-resident chunks: all levels in ONE launch
+            acc = LevelAccumulator(Legendre(R, dom), len(N))
+            chunks = [(l, torch.from_numpy(f[0].copy()).cuda(), None if c is None else torch.from_numpy(c[0].copy()).cuda())
+                      for l, (f, c) in enumerate(levels)]
+            got = acc.estimate(chunks, reduce=False)
+            assert np.array_equal(got[0], n) and np.array_equal(got[1], n_rm)
+            scale = np.sqrt(np.abs(sp) * np.maximum(n[:, None], 1))
+            assert close(got[2], s, scale, 1e-13) and close(got[3], sp, None, 1e-13)     # another grid split: other summation order
+            again = acc.estimate(chunks, reduce=False)
+            assert all(np.array_equal(a, bb) for a, bb in zip(again, got))               # run to run: bitwise
+    levels = level_arrays([9001, 5000, 1300], steps[:3], 1, 7)
+    bm = onp.Basis(onp.MONOMIAL, 52, (-3.7, 3.7))
+    n, n_rm, s, sp = _run_accum(Monomial(52, (-3.7, 3.7)), levels)
+    _check_against(n, n_rm, s, sp, onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(bm, x)))
+    # vector quantity (M = 3): keep flags come from the mask kernel
+    lv = level_arrays([6001, 3000, 1001], steps[:3], 3, 11)
+    b = onp.Basis(onp.LEGENDRE, 64, dom)
+    n, n_rm, s, sp = _run_accum(Legendre(64, dom), lv, n_comp=3)
+    _check_against(n, n_rm, s, sp, onp.estimate_mean(to_chunks(lv), lambda x: onp.moments_rows(b, x)))
+    # log transform (general loop)
+    rng = np.random.default_rng(5)
+    x = rng.lognormal(mean=0.3, sigma=0.8, size=30011)
+    f1, c1 = x * (1 + 0.01 * rng.normal(size=x.size)), x * (1 + 0.03 * rng.normal(size=x.size))
+    f1[::501] = -1.0
+    ll = [(x[None], None), (f1[None], c1[None])]
+    bl = onp.Basis(onp.LEGENDRE, 50, (0.05, 30.0), log=True)
+    n, n_rm, s, sp = _run_accum(Legendre(50, (0.05, 30.0), log=True), ll)
+    _check_against(n, n_rm, s, sp, onp.estimate_mean(to_chunks(ll), lambda v: onp.moments_rows(bl, v)))
+    # the two-pass form of the same build
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from mlmc_amd import _lib, Legendre\nfrom mlmc_amd.engine import LevelAccumulator\nfrom tests.util import level_arrays\n"
+            "_lib.init(0)\nlv = level_arrays([70001, 40099, 513, 2], [0.5, 0.1, 0.03, 0.01], 1, 5)\n"
+            "acc = LevelAccumulator(Legendre(64, (-3.7, 3.7)), 4)\n"
+            "[acc.push(l, f[0], None if c is None else c[0]) for l, (f, c) in enumerate(lv)]\n"
+            "n, n_rm, s, sp = acc.finalize()\nnp.savez(sys.argv[1], n=n, n_rm=n_rm, s=s, sp=sp)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "two_pass.npz")
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, MLMC_HIP_NO_SPLIT="1"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        two = np.load(out)
+    lv = level_arrays([70001, 40099, 513, 2], steps, 1, 5)
+    n, n_rm, s, sp = _run_accum(Legendre(64, dom), lv)
+    assert np.array_equal(two["n"], n) and np.array_equal(two["n_rm"], n_rm)
+    scale = np.sqrt(np.abs(sp) * np.maximum(n[:, None], 1))
+    assert close(s, two["s"], scale, 1e-13) and close(sp, two["sp"], None, 1e-13)
 
 
 def test_fourier_and_transformed_accumulate(hip):
@@ -394,17 +463,29 @@ def test_rccl_allreduce_path_single_rank(hip):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MLMC_HIP_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    # the default N = 1 workload: BASELINE configs[2] (covariance R = 64 through mlmc_accum_estimate_packed + the all-reduce)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["result_check"]["mean0"] == 1.0 and d["result_check"]["var0"] == 0.0
     assert d["n_gpus"] == 1 and d["value"] > 0
-    ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    assert d["config"]["estimate"] == "cov" and d["exchange"]["bytes_per_rank"] == 8 * (2 * 5 + 2 * 5 * 64 * 64)
+    ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"],
                          capture_output=True, text=True, timeout=600)
     d0 = json.loads([l for l in ref.stdout.splitlines() if l.startswith("{")][-1])
-    assert d0["result_check"] == d["result_check"]
+    assert d0["result_check"] == d["result_check"] and len(d["result_check"]["n_estimated"]) == 5
+    # the moments mode through the same path (BASELINE configs[1])
+    for e in (env, None):
+        o = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                           env=e, capture_output=True, text=True, timeout=600)
+        assert o.returncode == 0, o.stderr[-2000:]
+        dm = json.loads([l for l in o.stdout.splitlines() if l.startswith("{")][-1])
+        assert dm["result_check"]["mean0"] == 1.0 and dm["result_check"]["var0"] == 0.0
+        if e is None:
+            assert dm["result_check"] == last
+        last = dm["result_check"]
 
 
 def test_covariance_full_size_properties(hip):
