@@ -11,8 +11,12 @@
  * Conventions: every function returns 0 on success, non-zero on error (message through
  * mlmc_last_error(), thread-local).  The caller owns every buffer passed in; the library owns
  * its device scratch.  `mem_kind` says where a caller buffer lives (host or the bound device).
- * One process binds one device (one process per GPU) and the library works on ONE stream with shared workspaces:
- * calls must not overlap in time (serialise them if several host threads use the library); handles are not thread-safe.
+ * One process binds one device (one process per GPU) and the library works on ONE stream with shared workspaces.
+ * Thread safety: every entry point below (all but mlmc_last_error / mlmc_abi_version) takes one library-wide lock, so
+ * calls from several host threads are safe and are serialised in arrival order (bindings such as ctypes release the GIL
+ * during a call).  Distinct handles may be used from distinct threads concurrently; a multi-call sequence on ONE
+ * accumulator (reset ... push ... finalize) belongs to one thread at a time -- the one-call forms mlmc_accum_estimate /
+ * mlmc_accum_estimate_packed hold the lock for the whole estimate.
  * All floating point is IEEE fp64, all counts int64.  No CPU fallback exists: without a HIP
  * device every compute entry point fails.
  */

@@ -19,6 +19,10 @@ Runtime &rt() {
     static Runtime r;
     return r;
 }
+std::recursive_mutex &api_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
 
 int ensure(void **p, size_t *cap, size_t bytes) {
     if (bytes <= *cap && *p) return 0;
@@ -83,6 +87,7 @@ int mlmc_abi_version(void) { return MLMC_ABI_VERSION; }
 const char *mlmc_last_error(void) { return g_err.c_str(); }
 
 int mlmc_init(int device, int flags) {
+    MLMC_API_GUARD;
     Runtime &r = rt();
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -123,6 +128,7 @@ hipError_t wait_stream(hipStream_t st) {
 extern "C" {
 
 int mlmc_set_stream(void *stream) {
+    MLMC_API_GUARD;
     Runtime &r = rt();
     if (!r.ready) return fail("mlmc_init has not been called (no HIP device bound)");
     MLMC_HIP_CHECK(wait_stream(r.stream));
@@ -133,6 +139,7 @@ int mlmc_set_stream(void *stream) {
 }
 
 int mlmc_synchronize(void) {
+    MLMC_API_GUARD;
     Runtime &r = rt();
     if (!r.ready) return fail("mlmc_init has not been called (no HIP device bound)");
     MLMC_HIP_CHECK(wait_stream(r.stream));
@@ -140,6 +147,7 @@ int mlmc_synchronize(void) {
 }
 
 void mlmc_shutdown(void) {
+    MLMC_API_GUARD;
     Runtime &r = rt();
     if (!r.ready) return;
     (void)wait_stream(r.stream);
@@ -150,6 +158,7 @@ void mlmc_shutdown(void) {
 }
 
 int mlmc_device_info(char *name, int name_len, int *n_cu, int *wave_size, int64_t *hbm_bytes) {
+    MLMC_API_GUARD;
     if (need_runtime()) return 1;
     if (name && name_len > 0) {
         std::strncpy(name, rt().prop.name, (size_t)name_len - 1);
@@ -163,6 +172,7 @@ int mlmc_device_info(char *name, int name_len, int *n_cu, int *wave_size, int64_
 
 // ---- basis ---------------------------------------------------------------------------------
 int mlmc_basis_create(const mlmc_basis_desc *d, mlmc_basis **out) {
+    MLMC_API_GUARD;
     if (need_runtime()) return 1;
     if (!d || !out) return fail("mlmc_basis_create: null argument");
     if (d->size <= 0) return fail("mlmc_basis_create: size must be > 0");   // moments.py:11 assert size > 0
@@ -185,9 +195,10 @@ int mlmc_basis_create(const mlmc_basis_desc *d, mlmc_basis **out) {
     const int R = d->size;
     b->scale_c.assign(R, 1.0);
     if (d->kind == MLMC_LEGENDRE) {
-        long double c = 1.0L;   // leading coefficient of P_i: c_i = c_{i-1} (2i-1)/i
+        // P_i = c_i q_i with q_i = 2^i x (monic Legendre polynomial) (device_basis.hpp): c_i = c_{i-1} (2i-1) / (2i), c_0 = 1
+        long double c = 1.0L;
         for (int i = 0; i < R; ++i) {
-            if (i >= 2) c = c * (long double)(2 * i - 1) / (long double)i;
+            if (i >= 1) c = c * (long double)(2 * i - 1) / (long double)(2 * i);
             b->scale_c[i] = (double)c;
         }
     }
@@ -208,6 +219,7 @@ int mlmc_basis_create(const mlmc_basis_desc *d, mlmc_basis **out) {
 }
 
 void mlmc_basis_destroy(mlmc_basis *b) {
+    MLMC_API_GUARD;
     if (!b) return;
     if (b->d_scale) (void)hipFree(b->d_scale);
     if (b->d_matrix) (void)hipFree(b->d_matrix);
@@ -215,6 +227,7 @@ void mlmc_basis_destroy(mlmc_basis *b) {
 }
 
 int mlmc_basis_eval(const mlmc_basis *b, const double *x, int64_t n, int32_t size, double *out, int mem_kind) {
+    MLMC_API_GUARD;
     if (need_runtime()) return 1;
     if (!b || (n > 0 && (!x || !out))) return fail("mlmc_basis_eval: null argument");
     const int max_size = b->out_size > 0 ? b->out_size : b->p.size;
@@ -243,6 +256,7 @@ int mlmc_basis_eval(const mlmc_basis *b, const double *x, int64_t n, int32_t siz
 
 // ---- accumulators ---------------------------------------------------------------------------
 int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32_t n_comp, mlmc_accum **out) {
+    MLMC_API_GUARD;
     if (need_runtime()) return 1;
     if (!b || !out) return fail("mlmc_accum_create: null argument");
     if (n_levels <= 0 || n_comp <= 0) return fail("mlmc_accum_create: n_levels and n_comp must be > 0");
@@ -299,6 +313,7 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
 }
 
 int mlmc_accum_reset(mlmc_accum *a) {
+    MLMC_API_GUARD;
     if (need_runtime()) return 1;
     if (!a) return fail("mlmc_accum_reset: null argument");
     hipStream_t st = rt().stream;
@@ -309,6 +324,7 @@ int mlmc_accum_reset(mlmc_accum *a) {
 }
 
 void mlmc_accum_destroy(mlmc_accum *a) {
+    MLMC_API_GUARD;
     if (!a) return;
     if (rt().ready) (void)wait_stream(rt().stream);
     void *ptrs[] = {a->d_state, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c, a->d_mask, a->d_out, a->d_vals_f, a->d_vals_c};
@@ -320,6 +336,7 @@ void mlmc_accum_destroy(mlmc_accum *a) {
 }
 
 int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const double *coarse, int64_t n, int mem_kind) {
+    MLMC_API_GUARD;
     if (need_runtime()) return 1;
     if (!a) return fail("mlmc_accum_push: null argument");
     if (level < 0 || level >= a->n_levels) return fail("mlmc_accum_push: level out of range");
@@ -413,6 +430,7 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
 }
 
 int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, double *sp, int mem_kind) {
+    MLMC_API_GUARD;
     if (need_runtime()) return 1;
     if (!a || !n || !n_rm || !s || !sp) return fail("mlmc_accum_finalize: null argument");
     hipStream_t st = rt().stream;
@@ -465,6 +483,7 @@ int mlmc_accum_finalize(mlmc_accum *a, int64_t *n, int64_t *n_rm, double *s, dou
 int mlmc_accum_estimate(mlmc_accum *a, int32_t n_chunks, const int32_t *levels, const double *const *fine,
                         const double *const *coarse, const int64_t *n_samples, int mem_kind, int64_t *n, int64_t *n_rm,
                         double *s, double *sp) {
+    MLMC_API_GUARD;
     if (!a || n_chunks < 0 || (n_chunks > 0 && (!levels || !fine || !n_samples))) return fail("mlmc_accum_estimate: null argument");
     if (int rc = mlmc_accum_reset(a)) return rc;
     for (int k = 0; k < n_chunks; ++k)
@@ -473,6 +492,7 @@ int mlmc_accum_estimate(mlmc_accum *a, int32_t n_chunks, const int32_t *levels, 
 }
 
 int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind) {
+    MLMC_API_GUARD;
     if (need_runtime()) return 1;
     if (!a || !packed) return fail("mlmc_accum_finalize_packed: null argument");
     hipStream_t st = rt().stream;
@@ -500,6 +520,7 @@ int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind) {
 int mlmc_accum_estimate_packed(mlmc_accum *a, int32_t n_chunks, const int32_t *levels, const double *const *fine,
                                const double *const *coarse, const int64_t *n_samples, int mem_kind, double *packed,
                                int packed_kind) {
+    MLMC_API_GUARD;
     if (!a || n_chunks < 0 || (n_chunks > 0 && (!levels || !fine || !n_samples))) return fail("mlmc_accum_estimate_packed: null argument");
     if (int rc = mlmc_accum_reset(a)) return rc;
     for (int k = 0; k < n_chunks; ++k)
@@ -508,6 +529,7 @@ int mlmc_accum_estimate_packed(mlmc_accum *a, int32_t n_chunks, const int32_t *l
 }
 
 int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes) {
+    MLMC_API_GUARD;
     if (!a) return fail("mlmc_accum_kernel_time: null argument");
     if (a->ev_used) {   // the event pairs are read lazily, here: wait for the last one, then add them up
         MLMC_HIP_CHECK(hipEventSynchronize(a->ev[a->ev_used - 1]));

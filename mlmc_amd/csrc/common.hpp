@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,14 @@ int fail(const std::string &msg);
         if (_e != hipSuccess)                                                                  \
             return ::mlmc::fail(std::string(#expr) + ": " + hipGetErrorString(_e));            \
     } while (0)
+
+// One lock for the whole C ABI.  The library works on ONE stream with shared workspaces (the Runtime, the scratch and
+// staging buffers of an accumulator, the grow-only pools of the solver, the occupancy caches), so its entry points are
+// serialised: host threads may call in freely (ctypes releases the GIL), their calls queue up here.  Recursive because
+// the one-call forms (mlmc_accum_estimate, ...) go through other entry points.  Every extern "C" function that touches the
+// device takes it first (MLMC_API_GUARD); mlmc_last_error is thread-local and needs none.
+std::recursive_mutex &api_mutex();
+#define MLMC_API_GUARD std::lock_guard<std::recursive_mutex> mlmc_api_guard_(::mlmc::api_mutex())
 
 struct Runtime {
     bool ready = false;

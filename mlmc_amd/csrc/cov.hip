@@ -20,6 +20,17 @@
 namespace mlmc {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+#ifdef MLMC_PROF_COV   // diagnostic build only (tools/dev/prof_cov.hip): per-wave shader cycles of the phases and barrier waits
+__device__ unsigned long long *g_prof_cov;
+#define MLMC_COV_STAMP(slot)                                      \
+    {                                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        prof_acc[slot] += now_ - prof_t;                          \
+        prof_t = now_;                                            \
+    }
+#else
+#define MLMC_COV_STAMP(slot)
+#endif
 constexpr int COV_BATCH = 64;
 __host__ __device__ constexpr int cov_batch(int T, bool wide, bool vals) { return (T <= 2 && !wide && !vals) ? 128 : 64; }
 constexpr int COV_LDS_STRIDE = 66;   // doubles per term row: == 2 (mod 32) -> ds_read_b64 fragments hit 32 distinct bank pairs
@@ -95,6 +106,10 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
         int64_t idx = batch * BATCH + samp;
         if (idx < n) { xv = src[idx]; if (mask) mv = mask[idx]; }
     }
+#ifdef MLMC_PROF_COV
+    unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long prof_t0 = prof_t;
+#endif
     for (; batch < n_batches; batch += gridDim.x) {
         // ---------------- phase 1: moment values of this batch -> LDS ----------------
         if (VALS) {
@@ -136,7 +151,9 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
                 if (WIDE && i >= TB && i < TB + NT) dst_b[(i - TB) * STRIDE + samp] = q;
             }
         }
+        MLMC_COV_STAMP(0)
         __syncthreads();
+        MLMC_COV_STAMP(1)
         // ---------------- phase 2: MFMA over the batch ----------------
         if constexpr (SLICED) {
             const int rowl = lane & 15;
@@ -177,7 +194,9 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
                         }
                     }
             }
+            MLMC_COV_STAMP(2)
             __syncthreads();
+            MLMC_COV_STAMP(3)
             continue;
         }
         const int arow = 16 * I + (lane & 15);
@@ -220,6 +239,14 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
         __syncthreads();
     }
 
+#ifdef MLMC_PROF_COV
+    if (lane == 0 && blockIdx.y == 0) {
+        unsigned long long *q = g_prof_cov + ((size_t)blockIdx.x * 4 + wave) * 6;
+        q[0] = prof_acc[0]; q[1] = prof_acc[1]; q[2] = prof_acc[2]; q[3] = prof_acc[3];
+        q[4] = __builtin_amdgcn_s_memtime() - prof_t0;
+        q[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    }
+#endif
     // ---------------- write the workgroup's partial tiles ----------------
     // partial row = (block, kslice); columns [g][row][col] with g in {G0, G1, G2} (MODE 0) or {G} (MODE 1)
     constexpr int NGOUT = (MODE == 0) ? 3 : 1;
@@ -327,6 +354,10 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         int64_t idx = batch * COV_BATCH + samp;
         if (idx < n) { xv = src[idx]; if (mask) mv = mask[idx]; }
     }
+#ifdef MLMC_PROF_COV
+    unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long prof_t0 = prof_t;
+#endif
     for (; batch < n_batches; batch += gridDim.x) {
         if (evaluator) {
             const int64_t idx = batch * COV_BATCH + samp;
@@ -349,7 +380,9 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
                 if (i >= TA) dst[(i - TA) * COV_LDS_STRIDE + samp] = q;
             }
         }
+        MLMC_COV_STAMP(0)
         __syncthreads();
+        MLMC_COV_STAMP(1)
         __builtin_amdgcn_s_setprio(1);   // MFMA phase: issue ahead of the other workgroup's recurrence phase (+1 % MFMA time)
 #pragma unroll
         for (int ks = 0; ks < COV_BATCH / 4; ++ks) {
@@ -399,8 +432,18 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        MLMC_COV_STAMP(2)
         __syncthreads();
+        MLMC_COV_STAMP(3)
     }
+#ifdef MLMC_PROF_COV
+    if (lane == 0 && blockIdx.y == 0) {
+        unsigned long long *q = g_prof_cov + ((size_t)blockIdx.x * 4 + W) * 6;
+        q[0] = prof_acc[0]; q[1] = prof_acc[1]; q[2] = prof_acc[2]; q[3] = prof_acc[3];
+        q[4] = __builtin_amdgcn_s_memtime() - prof_t0;
+        q[5] = 0;
+    }
+#endif
 
     // ---- partial tiles: one row per block, columns [g][row][col]; symmetric tiles are mirrored here ----
     constexpr int NGOUT = (MODE == 0) ? 3 : 1;

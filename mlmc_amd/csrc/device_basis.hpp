@@ -32,15 +32,15 @@ __device__ __forceinline__ double transform_plain(const BasisParams &bp, double 
     return t;
 }
 
-// Monic Legendre recurrence coefficients g_i = (i-1)^2 / ((2i-1)(2i-3)) as a compile-time table: in the fully
-// unrolled accumulation kernels every index is a constant, so the values become instruction operands
-// (s_mov literals) instead of scalar loads that the wave would have to wait for inside the hot loop.
+// Coefficients 4 g_i, g_i = (i-1)^2 / ((2i-1)(2i-3)), of the scaled monic Legendre recurrence (TermGen below) as a
+// compile-time table: in the fully unrolled accumulation kernels every index is a constant, so the values become
+// instruction operands (s_mov literals) instead of scalar loads that the wave would have to wait for inside the hot loop.
 constexpr int LEGENDRE_MAX_TERMS = 512;
 struct LegendreG {
     double v[LEGENDRE_MAX_TERMS];
     constexpr LegendreG() : v() {
         for (int i = 0; i < LEGENDRE_MAX_TERMS; ++i)
-            v[i] = i < 2 ? 0.0 : (double)((long long)(i - 1) * (i - 1)) / (double)((long long)(2 * i - 1) * (2 * i - 3));
+            v[i] = i < 2 ? 0.0 : 4.0 * ((double)((long long)(i - 1) * (i - 1)) / (double)((long long)(2 * i - 1) * (2 * i - 3)));
     }
 };
 __device__ constexpr LegendreG kLegendreG = LegendreG();
@@ -50,13 +50,16 @@ __device__ constexpr LegendreG kLegendreG = LegendreG();
 //
 // LEGENDRE uses the monic recurrence Q_i = x Q_{i-1} - g_i Q_{i-2}, g_i = (i-1)^2 / ((2i-1)(2i-3)),
 // i.e. one multiply and one FMA per term instead of the five operations of
-// numpy.polynomial.legendre.legvander (P_i = (P_{i-1} x (2i-1) - P_{i-2} (i-1)) / i); the true
-// Legendre value is P_i = c_i Q_i with c_i the leading coefficient, applied once to the finished sums.
+// numpy.polynomial.legendre.legvander (P_i = (P_{i-1} x (2i-1) - P_{i-2} (i-1)) / i), in the scaled form
+// q_i = 2^i Q_i:  q_i = (2x) q_{i-1} - (4 g_i) q_{i-2}.  The monic Q_i shrink like 2^-i on [-1, 1] (their squares
+// would leave the normal fp64 range near i = 480), the q_i stay O(1) up to the largest accepted size; powers of two
+// scale exactly, so every q_i is bit for bit 2^i times the unscaled value.  The true Legendre value is
+// P_i = c_i q_i with c_i = (leading coefficient of P_i) / 2^i ~ 1 / sqrt(pi i), applied once to the finished sums.
 template <int KIND>
 struct TermGen {
     double x, p1, p2, c1, s1;
     __device__ __forceinline__ void init(double x_, double w, const BasisParams &) {
-        x = x_;
+        x = KIND == MLMC_LEGENDRE ? 2.0 * x_ : x_;
         p1 = w;   // term 0
         p2 = 0.0;
         if (KIND == MLMC_FOURIER) {

@@ -357,6 +357,7 @@ extern "C" {
 
 int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_regs, int32_t n_in_rows, int32_t n_out_rows,
                      mlmc_expr **out) {
+    MLMC_API_GUARD;
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!prog || !out) return fail("mlmc_expr_create: null argument");
     if (n_instr < 1 || n_instr > MLMC_EXPR_MAX_INSTR) return fail("mlmc_expr_create: program length out of range");
@@ -425,6 +426,7 @@ int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_reg
 }
 
 void mlmc_expr_destroy(mlmc_expr *e) {
+    MLMC_API_GUARD;
     if (!e) return;
     if (rt().ready) (void)wait_stream(rt().stream);
     void *ptrs[] = {e->d_prog, (void *)e->d_rows, e->d_tmp_f, e->d_tmp_c, e->d_keep, e->d_offsets};
@@ -437,6 +439,7 @@ void mlmc_expr_destroy(mlmc_expr *e) {
 
 int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coarse, int64_t n, int64_t sample_stride,
                    int64_t side_stride, double *fine_out, double *coarse_out, int64_t *n_selected) {
+    MLMC_API_GUARD;
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!e || !rows_in || !fine_out) return fail("mlmc_expr_eval: null argument");
     if (has_coarse && !coarse_out) return fail("mlmc_expr_eval: coarse_out is NULL");
@@ -535,6 +538,7 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
 }
 
 int mlmc_expr_kernel_time(mlmc_expr *e, double *ms, int64_t *launches, int64_t *alg_bytes) {
+    MLMC_API_GUARD;
     if (!e) return fail("mlmc_expr_kernel_time: null argument");
     if (e->ev_used) {
         MLMC_HIP_CHECK(hipEventSynchronize(e->ev[e->ev_used - 1]));

@@ -701,6 +701,7 @@ extern "C" {
 int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma, int32_t R1, double a, double bnd_b,
                       const mlmc_maxent_opts *opts, const double *prev_lambda, int32_t n_prev, double *lambda_io,
                       double *grad_out, double *hess_out, mlmc_maxent_info *info) {
+    MLMC_API_GUARD;
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!b || !mu || !sigma || !opts || !lambda_io || !info) return fail("mlmc_maxent_solve: null argument");
     const int max_out = b->out_size > 0 ? b->out_size : b->p.size;
@@ -940,6 +941,7 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
 
 int mlmc_density_eval(const mlmc_basis *b, const double *lambda, const double *sigma, int32_t R1, const double *x, int64_t n,
                       double *out, int mem_kind) {
+    MLMC_API_GUARD;
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!b || !lambda || !sigma || (n > 0 && (!x || !out))) return fail("mlmc_density_eval: null argument");
     const int max_out = b->out_size > 0 ? b->out_size : b->p.size;
@@ -979,6 +981,7 @@ int mlmc_density_eval(const mlmc_basis *b, const double *lambda, const double *s
 
 int mlmc_density_integrate(const mlmc_basis *b, const double *lambda, const double *sigma, int32_t R1, const double *lo,
                            const double *hi, int64_t n, int32_t degree, double *out) {
+    MLMC_API_GUARD;
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!b || !lambda || !sigma || (n > 0 && (!lo || !hi || !out))) return fail("mlmc_density_integrate: null argument");
     const int max_out = b->out_size > 0 ? b->out_size : b->p.size;

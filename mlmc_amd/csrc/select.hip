@@ -214,6 +214,7 @@ using namespace mlmc;
 
 extern "C" int mlmc_percentiles(const double *x, int64_t n, const double *q_percent, int32_t nq, double *out, int64_t *n_valid,
                                 int mem_kind) {
+    MLMC_API_GUARD;
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!x || !q_percent || !out || nq <= 0) return fail("mlmc_percentiles: bad argument");
     if (n <= 0) return fail("mlmc_percentiles: empty input");
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(256) void k_subsample_gather(const double *__restri
 
 extern "C" int mlmc_subsample_gather(const double *fine, const double *coarse, int32_t n_rows, int64_t n, int64_t k,
                                      uint64_t seed, double *fine_out, double *coarse_out) {
+    MLMC_API_GUARD;
     using namespace mlmc;
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!fine || !fine_out || (coarse && !coarse_out)) return fail("mlmc_subsample_gather: null argument");

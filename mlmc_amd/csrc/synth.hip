@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void k_synth(int level, int64_t first, int64_t
 }  // namespace mlmc
 
 extern "C" int mlmc_synth_seeds(int32_t level_id, int64_t first_sample, int64_t n, uint32_t *seeds_host) {
+    MLMC_API_GUARD;
     using namespace mlmc;
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!seeds_host || level_id < 0 || level_id > 999 || first_sample < 0 || n < 0) return fail("mlmc_synth_seeds: bad argument");
@@ -171,6 +172,7 @@ extern "C" int mlmc_synth_seeds(int32_t level_id, int64_t first_sample, int64_t 
 
 extern "C" int mlmc_synth_generate(int32_t level_id, int64_t first_sample, int64_t n, double fine_step, double coarse_step,
                                    double loc, double scale, int32_t n_rows, const int32_t *rows, double *const *out) {
+    MLMC_API_GUARD;
     using namespace mlmc;
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     if (!rows || !out) return fail("mlmc_synth_generate: null argument");

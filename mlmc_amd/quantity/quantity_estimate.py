@@ -9,6 +9,7 @@ ever materialised.
 """
 import collections
 import os
+import threading
 
 import numpy as np
 
@@ -445,8 +446,12 @@ def _subsample_on_device(pair, params):
     return out_f, out_c
 
 
+_estimate_lock = threading.RLock()
+
+
 def estimate_mean(quantity, group=None, variance=True):
-    """MLMC mean estimator (reference: quantity_estimate.py:22-80).
+    """MLMC mean estimator (reference: quantity_estimate.py:22-80).  Thread-safe: estimates of several host threads are
+    serialised (one GPU stream, one sample cache, the memo of chunk evaluations shared by all quantities).
 
     :param quantity: Quantity
     :param group: optional torch.distributed process group; when a group (or the default group) with more than one
@@ -455,6 +460,11 @@ def estimate_mean(quantity, group=None, variance=True):
                   exist for the variances alone are skipped and the corresponding variances come back as NaN.
     :return: QuantityMean
     """
+    with _estimate_lock:
+        return _estimate_mean(quantity, group, variance)
+
+
+def _estimate_mean(quantity, group, variance):
     cache_clear()
     quantity_vec_size = quantity.size()
     storage_q = quantity.get_quantity_storage()

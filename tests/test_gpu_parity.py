@@ -232,6 +232,29 @@ def test_moment_counts_and_multi_pass(hip, R):
     assert s[0, 0] == float(n[0])                     # P0 sums are exact counts
 
 
+def test_largest_accepted_legendre_size(hip):
+    """512 Legendre moments, the largest size mlmc_basis_create accepts: the device recurrence runs on q_i = 2^i Q_i (the
+    monic Q_i themselves shrink like 2^-i, their squares would be subnormal from i ~ 480), values and level sums of the top
+    moments against legvander (oracle)."""
+    from mlmc_amd import Legendre
+    dom = (-3.7, 3.7)
+    R = 512
+    fn = Legendre(R, dom)
+    grid = np.linspace(dom[0], dom[1], 1501)
+    got = fn.eval_all(grid)
+    ref = onp.eval_all(onp.Basis(onp.LEGENDRE, R, dom), grid)
+    assert got.shape == ref.shape and np.all(np.abs(got - ref) <= 1e-11)
+    assert np.max(np.abs(got[:, -16:])) > 0.01                                    # the top columns are not flushed to zero
+    levels = level_arrays([3001, 1500], [0.3, 0.02], 1, 7)
+    n, n_rm, s, sp = _run_accum(fn, levels)
+    b = onp.Basis(onp.LEGENDRE, R, dom)
+    ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(b, x))
+    assert np.array_equal(n, ref.n_samples) and np.array_equal(n_rm, ref.n_rm_samples)
+    scale = np.sqrt(np.abs(ref.sums_sq) * ref.n_samples[:, None])
+    assert close(s, ref.sums, scale, 1e-10) and close(sp, ref.sums_sq, None, 1e-10)
+    assert np.all(sp[:, -32:] > 1e-3)                                              # sums of squares of the top moments survive
+
+
 def test_term_split_kernel_for_49_to_64_moments(hip):
     """48 < R <= 64 of a polynomial family runs k_moments_accum_split (waves 0-1: terms 0..31, waves 2-3: terms 32..63 of the
     same samples, recurrence state handed over through LDS): ragged and tiny sizes (fewer samples than a workgroup has

@@ -1,0 +1,75 @@
+// Diagnostic (not part of the library): per-wave shader cycles of the phases of k_cov_accum<LEGENDRE, T = 2, pair> (R <= 32):
+// phase 1 (evaluation), wait at the barrier behind it, phase 2 (MFMA), wait at the barrier behind it.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DMLMC_PROF_COV -I include -I mlmc_amd/csrc
+//        tools/dev/prof_cov.hip mlmc_amd/csrc/api.hip mlmc_amd/csrc/moments.hip mlmc_amd/csrc/maxent.hip mlmc_amd/csrc/select.hip
+//        mlmc_amd/csrc/expr.hip mlmc_amd/csrc/synth.hip -o tools/dev/prof_cov
+#include "../../mlmc_amd/csrc/cov.hip"
+#include <algorithm>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+using namespace mlmc;
+
+template <int T, int MODE, bool PAIR = true>
+static void run(const char *name, const BasisParams &bp, const double *f, const double *c, int64_t n, int blocks) {
+    constexpr int NT = 16 * T;
+    double *partials; unsigned long long *prof;
+    (void)hipMalloc(&partials, sizeof(double) * (size_t)blocks * 4 * 3 * NT * NT);
+    (void)hipMalloc(&prof, sizeof(unsigned long long) * (size_t)blocks * 4 * 6);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_cov), &prof, sizeof(prof));
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float ms = 0;
+    for (int it = 0; it < 60; ++it) {
+        (void)hipEventRecord(e0);
+        if constexpr (T == 4)
+            hipLaunchKernelGGL((k_cov_accum_t4<MLMC_LEGENDRE, PAIR, MODE, 0>), dim3(blocks), dim3(256), 0, 0, bp, f, PAIR ? c : nullptr, nullptr, n, bp.size, partials, nullptr);
+        else
+            hipLaunchKernelGGL((k_cov_accum<MLMC_LEGENDRE, T, PAIR, MODE>), dim3(blocks), dim3(256), 0, 0, bp, f, PAIR ? c : nullptr, nullptr, n, bp.size, partials, nullptr);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+    }
+    std::vector<unsigned long long> p((size_t)blocks * 4 * 6);
+    (void)hipMemcpy(p.data(), prof, sizeof(unsigned long long) * p.size(), hipMemcpyDeviceToHost);
+    double sum[5] = {0, 0, 0, 0, 0};
+    for (size_t w = 0; w < (size_t)blocks * 4; ++w)
+        for (int k = 0; k < 5; ++k) sum[k] += (double)p[w * 6 + k];
+    const double nw = (double)blocks * 4;
+    const int64_t bsz = T == 4 ? COV_BATCH : cov_batch(T, false, false);
+    const double batches_per_wg = (double)((n + bsz - 1) / bsz) / blocks;
+    printf("%s: kernel %.3f ms; per wave and batch (cycles): phase1 %.0f  barrier1 %.0f  phase2 %.0f  barrier2 %.0f  total %.0f  (%.1f batches per workgroup)\n",
+           name, ms, sum[0] / nw / batches_per_wg, sum[1] / nw / batches_per_wg, sum[2] / nw / batches_per_wg,
+           sum[3] / nw / batches_per_wg, sum[4] / nw / batches_per_wg, batches_per_wg);
+    (void)hipFree(partials);
+    (void)hipFree(prof);
+}
+
+int main(int argc, char **argv) {
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 10000000;
+    std::vector<double> h(n), hc(n);
+    std::mt19937_64 g(1);
+    std::normal_distribution<double> nd;
+    for (int64_t i = 0; i < n; ++i) { h[i] = nd(g); hc[i] = h[i] + 0.05 * nd(g); }
+    double *f, *c;
+    (void)hipMalloc(&f, sizeof(double) * n); (void)hipMalloc(&c, sizeof(double) * n);
+    (void)hipMemcpy(f, h.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+    (void)hipMemcpy(c, hc.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+    BasisParams bp{};
+    bp.kind = MLMC_LEGENDRE; bp.size = 32; bp.shift = -3.7190164854556804; bp.scale = 2.0 / (2 * 3.7190164854556804);
+    bp.ref0 = -1; bp.ref1 = 1; bp.is_log = 0; bp.is_clip = 1;
+    run<2, 0>("T=2 pair, mean+var", bp, f, c, n, 512);
+    run<2, 0>("T=2 pair, mean+var", bp, f, c, n, 512);
+    run<2, 2>("T=2 pair, mean only", bp, f, c, n, 512);
+    run<2, 0, false>("T=2 level 0, mean+var", bp, f, c, n, 512);
+    run<2, 2, false>("T=2 level 0, mean only", bp, f, c, n, 512);
+    bp.size = 64;
+    run<4, 0>("T=4 pair, mean+var", bp, f, c, n, 512);
+    run<4, 2>("T=4 pair, mean only", bp, f, c, n, 512);
+    run<4, 0, false>("T=4 level 0, mean+var", bp, f, c, n, 512);
+    run<4, 2, false>("T=4 level 0, mean only", bp, f, c, n, 512);
+    bp.size = 16;
+    run<1, 0>("T=1 pair, mean+var (4 workgroups per CU)", bp, f, c, n, 1024);
+    run<1, 2>("T=1 pair, mean only (4 workgroups per CU)", bp, f, c, n, 1024);
+    return 0;
+}

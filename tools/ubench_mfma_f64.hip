@@ -25,7 +25,9 @@ __global__ __launch_bounds__(256) void k(double *out, double a, double b, int it
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < NACC * RUN; ++u) {
-            acc[u / RUN] = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb, acc[u / RUN], 0, 0, 0);
+            // inline asm pins the accumulators to VGPRs: with the builtin hipcc parks loop-carried accumulators in AGPRs and
+            // copies all of them in and out every iteration (176 v_accvgpr moves at 11 accumulators), which swamps the figure
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[u / RUN]) : "v"(va), "v"(vb));
 #pragma unroll
             for (int v = 0; v < NV; ++v) {   // two independent recurrences, alternating
                 if (v & 1) { const double t = __builtin_fma(x, q1, -(0.25 * q2)); q2 = q1; q1 = t; }
