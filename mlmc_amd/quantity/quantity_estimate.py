@@ -163,6 +163,8 @@ def _lib_device():
 
 
 _device_cache = _DeviceChunkCache()
+# One estimate at a time: one GPU stream, one sample cache, one memo of chunk evaluations shared by all quantities.
+_estimate_lock = threading.RLock()
 
 
 _cache_generation = 0
@@ -175,15 +177,18 @@ def device_cache_generation():
 
 
 def device_cache_clear():
-    """Drop the HBM-resident sample chunks (call after modifying stored samples in place)."""
+    """Drop the HBM-resident sample chunks (call after modifying stored samples in place).  Waits for a running estimate of
+    another thread: its kernels may still read the resident rows."""
     global _cache_generation
-    _cache_generation += 1
-    _device_cache.clear()
+    with _estimate_lock:
+        _cache_generation += 1
+        _device_cache.clear()
 
 
 def device_cache_drop_owner(storage):
     """Drop the resident chunks that came from one storage (it changed: grew, was refilled)."""
-    _device_cache.drop_owner(storage)
+    with _estimate_lock:
+        _device_cache.drop_owner(storage)
 
 
 def _split_fine_coarse(chunk, level_id):
@@ -318,8 +323,9 @@ def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache):
     blk = _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache)
     if blk is not None:
         t, sn, sw, n, width = blk
+        # without the cache nothing keeps the uploaded block alive past this call: wait for the kernel that reads it
         fine, coarse, _ = plan.evaluate([t[r:] for r in plan.in_rows], has_coarse=(width == 2), n=n, sample_stride=sn,
-                                        side_stride=max(sw, 1))
+                                        side_stride=max(sw, 1), sync=not use_cache)
         return fine, coarse
     rows = [_stored_row_on_device(plan, chunk_spec, chunk_key, r, use_cache) for r in plan.in_rows]
     n, width = rows[0].shape
@@ -327,7 +333,7 @@ def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache):
         return None
     if width == 1 and plan.is_row_copy:
         return rows[0].view(1, n), None         # a level-0 row already is the contiguous fine array: no kernel, no copy
-    fine, coarse, _ = plan.evaluate(rows, has_coarse=(width == 2), n=n)
+    fine, coarse, _ = plan.evaluate(rows, has_coarse=(width == 2), n=n, sync=not use_cache)
     return fine, coarse
 
 
@@ -407,6 +413,11 @@ def fine_samples_for_device(quantity, chunk_spec):
     """Fine values of one chunk of `quantity` where the device wants them: a torch CUDA tensor when the tree is lowered
     (stored rows resident or generated in HBM, nothing crosses PCIe), else the host array of the host-evaluated tree.
     Used by Estimate.estimate_domain (percentiles of the fine samples)."""
+    with _estimate_lock:
+        return _fine_samples_for_device(quantity, chunk_spec)
+
+
+def _fine_samples_for_device(quantity, chunk_spec):
     plan = lowering.plan_for(quantity) if _device_tree_enabled() else None
     if plan is None:
         return np.squeeze(quantity.samples(chunk_spec)[..., 0])
@@ -444,9 +455,6 @@ def _subsample_on_device(pair, params):
         _lib.check(_lib.lib().mlmc_subsample_gather(fine.data_ptr(), None if coarse is None else coarse.data_ptr(), m, n, size,
                                                     seed, out_f.data_ptr(), None if out_c is None else out_c.data_ptr()))
     return out_f, out_c
-
-
-_estimate_lock = threading.RLock()
 
 
 def estimate_mean(quantity, group=None, variance=True):

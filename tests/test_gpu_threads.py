@@ -29,14 +29,14 @@ def _run_threads(workers):
             except BaseException as e:          # noqa: BLE001 - reported to the test thread
                 errors.append(e)
         return run
-    threads = [threading.Thread(target=guard(w)) for w in workers]
+    threads = [threading.Thread(target=guard(w), daemon=True) for w in workers]      # daemon: a stuck worker cannot keep the process
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=300)
-    assert not any(t.is_alive() for t in threads), "a worker thread hangs"
+        t.join(timeout=120)
     if errors:
         raise errors[0]
+    assert not any(t.is_alive() for t in threads), "a worker thread hangs"
 
 
 def test_concurrent_estimates_through_the_c_abi(hip):
@@ -125,9 +125,11 @@ def test_concurrent_estimates_through_the_python_api(hip):
             out["a"].append(analysis(qa, fa))
 
     def run_b():
-        for _ in range(15):
-            out["b"].append(analysis(qb, fb))
-        stop.set()
+        try:
+            for _ in range(15):
+                out["b"].append(analysis(qb, fb))
+        finally:
+            stop.set()
 
     def clearer():
         while not stop.wait(0.01):
