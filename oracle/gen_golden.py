@@ -320,6 +320,25 @@ def g5_g6():
                 out5[tk + "_eval"] = ev
                 out5[tk + "_threshold"] = np.array(thr)
                 out5[tk + "_L"] = L_mn
+            # tol=None: threshold from the change of slope of the log-eigenvalues (simple_distribution.py:781-782, :584-609).
+            # An exact covariance has eigenvalues down at rounding level (some negative); covariances estimated from samples
+            # -- the case the rule is made for -- are emulated by a small symmetric perturbation with a fixed seed.
+            for tag, noise in (("none", 0.0), ("none_n6", 1e-6), ("none_n4", 1e-4)):
+                rng = np.random.default_rng(20 + R)
+                E = rng.standard_normal(cov.shape)
+                cov_n = cov + noise * (E + E.T) / 2
+                cov_n[0, :] = cov[0, :]
+                cov_n[:, 0] = cov[:, 0]
+                tk = key + "_tol" + tag
+                try:
+                    ortho_n, (ev, thr, L_mn) = sd.construct_ortogonal_moments(base, cov_n.copy(), None)
+                except Exception as e:       # recorded: the port has to fail the same way
+                    out5[tk + "_error"] = np.array(type(e).__name__)
+                    continue
+                out5[tk + "_cov"] = cov_n
+                out5[tk + "_eval"] = ev
+                out5[tk + "_threshold"] = np.array(thr)
+                out5[tk + "_L"] = L_mn
             ortho, (ev, thr, L_mn) = sd.construct_ortogonal_moments(base, cov, 1e-4 if name != "lognorm" else 1e-3)
             exact_moments = sd.compute_semiexact_moments(ortho, pdf)
             moment_data = np.stack([exact_moments, np.ones_like(exact_moments)], axis=1)
@@ -338,8 +357,16 @@ def g5_g6():
             out6[key + "_sd_cdf"] = d.cdf(xg[::8])
             out6[key + "_exact_pdf"] = pdf(xg)
             out6[key + "_sd_nquad"] = np.array(len(d._quad_points))
-            print("G6", key, "nit", res.nit, "fun_norm", res.fun_norm, "Q", len(d._quad_points),
-                  "KL", sd.KL_divergence(pdf, d.density, domain[0], domain[1]))
+            # diagnostics of simple_distribution.py:330-464 on the reference's own reconstruction
+            kl = sd.KL_divergence(pdf, lambda x: float(d.density(x)[0]), domain[0], domain[1])
+            out6[key + "_sd_KL"] = np.array(kl)
+            out6[key + "_sd_L2"] = np.array(sd.L2_distance(pdf, lambda x: float(d.density(x)[0]), domain[0], domain[1]))
+            if R == 7:
+                out6[key + "_exact_moments"] = sd.compute_exact_moments(base, pdf)
+                out6[key + "_exact_cov"] = sd.compute_exact_cov(base, pdf)
+                out6[key + "_semiexact_moments_base"] = sd.compute_semiexact_moments(base, pdf)
+                out6[key + "_old_exact_moments"] = dd.compute_exact_moments(base, pdf)
+            print("G6", key, "nit", res.nit, "fun_norm", res.fun_norm, "Q", len(d._quad_points), "KL", kl)
         # older solver (tool/distribution.py) on plain Legendre moments with small noise-free data
         for R in (5, 11):
             base = mm.Legendre(R, domain)
@@ -357,6 +384,9 @@ def g5_g6():
             out6[key + "_fun_norm"] = np.array(res.fun_norm)
             out6[key + "_xgrid"] = xg
             out6[key + "_density"] = d.density(xg)
+            out6[key + "_end_diff"] = np.dot(d._end_point_diff, res.x)       # > 0: the decay penalty is active at the solution
+            out6[key + "_KL"] = np.array(dd.KL_divergence(pdf, lambda x: float(d.density(x)[0]), domain[0], domain[1]))
+            out6[key + "_L2"] = np.array(dd.L2_distance(pdf, lambda x: float(d.density(x)[0]), domain[0], domain[1]))
             print("G6 old", key, "nit", res.nit, "fun_norm", res.fun_norm)
     np.savez_compressed(os.path.join(OUT, "G5_ortho.npz"), **out5)
     np.savez_compressed(os.path.join(OUT, "G6_maxent.npz"), **out6)

@@ -124,8 +124,8 @@ def test_orthogonal_moments_host():
     from mlmc_amd import Legendre, TransformedMoments
     from mlmc_amd.tool import simple_distribution as sd
     g5 = np.load(os.path.join(GOLDEN, "G5_ortho.npz"))
-    for name in ("norm12", "lognorm"):
-        for R in (7, 41):
+    for name in ("norm12", "norm110", "lognorm"):
+        for R in (7, 21, 41):
             key = f"{name}_R{R}"
             base = Legendre(R, tuple(g5[key + "_domain"]))
             cov = g5[key + "_cov"]
@@ -137,8 +137,14 @@ def test_orthogonal_moments_host():
                 assert np.allclose(L, g5[tk + "_L"], rtol=1e-7, atol=1e-9)
             ortho, (ev, thr, L) = sd.construct_ortogonal_moments(base, cov, 1e-4)
             assert np.linalg.norm(L @ cov @ L.T - np.eye(L.shape[0])) < 1e-8      # test/test_distribution.py:180 (1e-10 there on exact cov)
-            ortho2, info2 = sd.construct_ortogonal_moments(base, cov, tol=None)    # slope-change threshold detector runs
-            assert 0 <= info2[1] < R
+            # tol=None: the slope-change threshold (simple_distribution.py:781-782) on exact and perturbed covariances
+            for tag in ("none", "none_n6", "none_n4"):
+                tk = key + "_tol" + tag
+                ortho2, (ev2, thr2, L2) = sd.construct_ortogonal_moments(base, g5[tk + "_cov"].copy(), tol=None)
+                assert thr2 == int(g5[tk + "_threshold"]), tk
+                assert np.allclose(ev2, g5[tk + "_eval"], rtol=1e-9, atol=1e-13)
+                assert L2.shape == g5[tk + "_L"].shape and np.allclose(L2, g5[tk + "_L"], rtol=1e-6, atol=1e-8), tk
+                assert ortho2.size == L2.shape[0]
 
 
 def test_moments_objects_host_side():

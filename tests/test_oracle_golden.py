@@ -196,6 +196,14 @@ def test_orthogonal_moments():
             # test/test_distribution.py:180: ||L cov L^T - I|| < 1e-10 for the kept directions
             L, ev, thr = onp.construct_orthogonal_matrix(cov, 1e-4)
             assert np.linalg.norm(L @ cov @ L.T - np.eye(L.shape[0])) < 1e-8
+            # tol=None: threshold from the slope change of the log-eigenvalues (exact and perturbed covariances)
+            for tag in ("none", "none_n6", "none_n4"):
+                tk = key + "_tol" + tag
+                assert tk + "_error" not in g5.files
+                L, ev, thr = onp.construct_orthogonal_matrix(g5[tk + "_cov"], None)
+                assert thr == int(g5[tk + "_threshold"]), tk
+                assert np.allclose(ev, g5[tk + "_eval"], rtol=1e-9, atol=1e-13)
+                assert L.shape == g5[tk + "_L"].shape and np.allclose(L, g5[tk + "_L"], rtol=1e-6, atol=1e-8), tk
 
 
 @pytest.mark.parametrize("key", ["norm12_R7", "norm12_R21", "norm110_R21", "lognorm_R21"])
