@@ -252,6 +252,62 @@ def exchange_block(fn, L, R, ctx, reps=50):
             "note": "all-reduce + copy of the reduced sums to the host, timed alone; inside a step it follows the kernels on the same stream"}
 
 
+def h2d_inclusive_block():
+    """the first estimate over samples that still sit in a host storage, delivered the way SampleStorageHDF
+    delivers them -- 300 chunks of 1e5 samples (3 levels x 1e7), every chunk a freshly allocated [n, 2, M] array
+    (Memory(copy_chunks=True) stands in for the HDF5 reads; h5py is not part of the image).  `stream` (the default feed): a
+    helper thread reads the chunks ahead while the main thread uploads and launches; `sync`: read, upload, launch one after
+    the other (MLMC_HIP_STREAM_UPLOAD=0); `pinned`: pinned staging ring + asynchronous DMA on a copy stream, kernels ordered
+    behind it by mlmc_wait_event (MLMC_HIP_STREAM_UPLOAD=pinned); `resident`: the next estimate, from HBM.  PCIe-inclusive
+    figures are never the headline `value`."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate, determine_level_parameters
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.quantity.quantity_spec import QuantitySpec
+    from mlmc_amd.sample_storage import Memory
+    L, n_l, chunk, R = 3, 10_000_000, 100_000, 32
+    steps_h = [s[0] for s in determine_level_parameters(L, [0.5, 0.01])]
+    spec = [QuantitySpec(name="q", unit="", shape=(1, 1), times=[1], locations=['0'])]
+    st = Memory(chunk_size=chunk, copy_chunks=True)
+    st.save_global_data(result_format=spec, level_parameters=[[h] for h in steps_h])
+    for l in range(L):
+        x = np.random.default_rng(99 + l).standard_normal(n_l)
+        root = np.sqrt(1e-4 + np.abs(x))
+        st.set_level_samples(l, x + steps_h[l] * root, None if l == 0 else x + steps_h[l - 1] * root)
+    q = make_root_quantity(st, spec)['q'][1]['0'][0, 0]
+    est = Estimate(q, st, Legendre(R, DOMAIN))
+    out = {"workload": "3 levels x 1e7 samples in a host storage, 300 chunks of 1e5 samples, Legendre n_moments=32 mean+var estimate",
+           "chunks": L * (n_l // chunk), "host_bytes": int(L * n_l * 16)}
+    saved = os.environ.get("MLMC_HIP_STREAM_UPLOAD")
+    results = {}
+    try:
+        for mode, flag in (("stream", "1"), ("sync", "0"), ("pinned", "pinned")):
+            os.environ["MLMC_HIP_STREAM_UPLOAD"] = flag
+            times = []
+            for _ in range(3):
+                qe.device_cache_clear()
+                t0 = time.perf_counter()
+                results[mode] = est.estimate_moments()
+                times.append(time.perf_counter() - t0)
+            out[mode + "_ms"] = round(1e3 * min(times), 3)
+            out[mode + "_gbs"] = round(out["host_bytes"] / min(times) / 1e9, 2)
+            out[mode + "_evals_per_s"] = L * n_l * R / min(times)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            warm = est.estimate_moments()
+        out["resident_ms"] = round(1e3 * (time.perf_counter() - t0) / 5, 3)
+        out["same_result"] = bool(all(np.array_equal(a, b) for r in ("sync", "pinned") for a, b in zip(results["stream"], results[r]))
+                                  and all(np.array_equal(a, b) for a, b in zip(results["stream"], warm)))
+    finally:
+        if saved is None:
+            os.environ.pop("MLMC_HIP_STREAM_UPLOAD", None)
+        else:
+            os.environ["MLMC_HIP_STREAM_UPLOAD"] = saved
+        qe.device_cache_clear()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -387,6 +443,7 @@ def main():
             out[name] = blk
             del d2
             torch.cuda.empty_cache()
+        out["h2d_inclusive"] = h2d_inclusive_block()
     finish(out)
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MLMC_ABI_VERSION 2   /* 2: strides in mlmc_expr_eval, chaining flags, mlmc_accum_estimate_packed */
+#define MLMC_ABI_VERSION 3   /* 2: strides in mlmc_expr_eval, chaining flags, mlmc_accum_estimate_packed; 3: mlmc_wait_event */
 
 /* basis kinds -- mlmc/moments.py: Legendre :174-229, Monomial :111-130, Fourier :133-171;
  * IDENTITY = the quantity itself (estimate_mean of a plain quantity, quantity_estimate.py:22-80);
@@ -72,6 +72,11 @@ void mlmc_shutdown(void);
 /* Run all later work on the caller's HIP stream (e.g. the stream RCCL collectives are enqueued on), so that
  * mlmc_accum_finalize_packed(..., MLMC_DEVICE) followed by an all-reduce needs no host synchronisation in between. */
 int mlmc_set_stream(void *hip_stream);
+/* Make the library's stream wait for a HIP event recorded on another stream of the same device (asynchronous for the
+ * host): the feed of a storage that arrives in many chunks (SampleStorageHDF: one `collected_values[chunk_slice]` read per
+ * chunk, mlmc/tool/hdf5.py:353-376) copies chunk k + 1 from pinned host memory on a copy stream while the kernels of chunk k
+ * run here; every later launch of the library is ordered behind the event. */
+int mlmc_wait_event(void *hip_event);
 /* Wait until everything the library has enqueued on its stream is done (asynchronous entry points: mlmc_accum_push
  * with device buffers, mlmc_expr_eval, mlmc_accum_finalize_packed(MLMC_DEVICE)). */
 int mlmc_synchronize(void);

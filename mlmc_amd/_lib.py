@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLMC_HIP_LIB", os.path.join(_HERE, "libmlmc_hip.so"))   # env override: development builds
 
-ABI_VERSION = 2      # MLMC_ABI_VERSION of include/mlmc_hip.h
+ABI_VERSION = 3      # MLMC_ABI_VERSION of include/mlmc_hip.h
 LEGENDRE, MONOMIAL, FOURIER, IDENTITY, SPLINE = 0, 1, 2, 3, 4
 MODE_MOMENTS, MODE_COV = 0, 1
 MODE_MEAN_ONLY = 0x100
@@ -51,6 +51,7 @@ SIGNATURES = {
     "mlmc_shutdown": (None, []),
     "mlmc_set_stream": (C.c_int, [_vp]),
     "mlmc_synchronize": (C.c_int, []),
+    "mlmc_wait_event": (C.c_int, [_vp]),
     "mlmc_last_error": (C.c_char_p, []),
     "mlmc_abi_version": (C.c_int, []),
     "mlmc_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _ip]),

@@ -138,6 +138,15 @@ int mlmc_set_stream(void *stream) {
     return 0;
 }
 
+int mlmc_wait_event(void *hip_event) {
+    MLMC_API_GUARD;
+    Runtime &r = rt();
+    if (!r.ready) return fail("mlmc_init has not been called (no HIP device bound)");
+    if (!hip_event) return fail("mlmc_wait_event: null event");
+    MLMC_HIP_CHECK(hipStreamWaitEvent(r.stream, (hipEvent_t)hip_event, 0));
+    return 0;
+}
+
 int mlmc_synchronize(void) {
     MLMC_API_GUARD;
     Runtime &r = rt();

@@ -119,10 +119,8 @@ class _DeviceChunkCache:
         while self._bytes + nbytes > self.budget() and self._items:
             _, (_, _, old, _) = self._items.popitem(last=False)
             self._bytes -= old
-        dev = torch.device("cuda", _lib_device())
         # `owner` (the source quantity) is kept alive with the entry, so its id() in the key cannot be re-used
-        item = (torch.from_numpy(fine).to(dev), None if coarse is None else torch.from_numpy(coarse).to(dev), nbytes, owner)
-        torch.cuda.current_stream(dev).synchronize()    # the library reads them on its own stream
+        item = (_upload(fine, count=False), None if coarse is None else _upload(coarse, count=False), nbytes, owner)
         self._items[key] = item
         self._bytes += nbytes
         self.uploads += 1
@@ -183,12 +181,141 @@ def device_cache_clear():
     with _estimate_lock:
         _cache_generation += 1
         _device_cache.clear()
+        _block_meta.clear()
 
 
 def device_cache_drop_owner(storage):
     """Drop the resident chunks that came from one storage (it changed: grew, was refilled)."""
     with _estimate_lock:
         _device_cache.drop_owner(storage)
+
+
+class _StagingRing:
+    """Pinned staging for uploads of storage chunks, opt-in with MLMC_HIP_STREAM_UPLOAD=pinned.
+
+    N pinned host buffers, one copy stream, one event per buffer.  A chunk is copied into the next free pinned buffer,
+    sent to HBM with an asynchronous DMA on the copy stream, and the library's stream is told to wait for that DMA
+    (mlmc_wait_event) -- the host does not wait for the transfer.  A buffer is reused when the DMA that read it has
+    completed.  Chunks above MLMC_HIP_STREAM_CHUNK_MB (default 32) skip the ring.
+    Measured on the MI355X boxes of this pool (tools/dev/gpu_stream_dev.py, 300 chunks of 1.6 MB): the extra host copy
+    into the pinned buffer runs at 4.5 GB/s and queueing one asynchronous copy + event costs 0.2-0.4 ms of host time --
+    as much as the whole synchronous pageable copy of the chunk (0.17-0.34 ms, the runtime stages it through its own
+    pinned buffers).  The ring is therefore NOT the default feed: the default overlaps the storage reads with the
+    uploads instead (_ChunkPrefetcher below); the ring remains for hosts where pinned staging pays."""
+
+    def __init__(self, n_slots=3):
+        self._n = n_slots
+        self._pinned = [None] * n_slots
+        self._events = [None] * n_slots
+        self._next = 0
+        self._stream = None
+        self.chunks = 0
+
+    @staticmethod
+    def enabled():
+        return os.environ.get("MLMC_HIP_STREAM_UPLOAD", "1") == "pinned"
+
+    @staticmethod
+    def limit_bytes():
+        return int(float(os.environ.get("MLMC_HIP_STREAM_CHUNK_MB", "32")) * 2 ** 20)
+
+    def upload(self, flat):
+        """flat: contiguous 1-D float64 host array -> device tensor of the same length.  Returns as soon as the DMA is
+        queued; everything the library launches afterwards is ordered behind it."""
+        import torch
+        from .. import _lib
+        dev = torch.device("cuda", _lib_device())
+        n = flat.size
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        slot = self._next
+        self._next = (slot + 1) % self._n
+        if self._events[slot] is not None:
+            self._events[slot].synchronize()                     # the DMA that last read this buffer
+        buf = self._pinned[slot]
+        if buf is None or buf.numel() < n:
+            buf = self._pinned[slot] = torch.empty(max(n, 1 << 16), dtype=torch.float64, pin_memory=True)
+        buf[:n].copy_(torch.from_numpy(flat))
+        out = torch.empty(n, dtype=torch.float64, device=dev)
+        ev = self._events[slot]
+        if ev is None:
+            ev = self._events[slot] = torch.cuda.Event()
+        with torch.cuda.stream(self._stream):
+            out.copy_(buf[:n], non_blocking=True)
+            ev.record(self._stream)
+        _lib.check(_lib.lib().mlmc_wait_event(ev.cuda_event))
+        self.chunks += 1
+        return out
+
+    def drain(self):
+        for ev in self._events:
+            if ev is not None:
+                ev.synchronize()
+
+
+_staging = _StagingRing()
+
+
+def _upload(host_array, count=True):
+    """Host array (any shape, float64, C-contiguous) -> device tensor of the same shape: through the staging ring when the
+    chunk is small, as one synchronous pageable copy otherwise."""
+    import torch
+    a = np.ascontiguousarray(host_array, dtype=np.float64)
+    if count:
+        _device_cache.uploads += 1
+    if _StagingRing.enabled() and 0 < a.nbytes <= _StagingRing.limit_bytes():
+        return _staging.upload(a.reshape(-1)).view(a.shape)
+    dev = torch.device("cuda", _lib_device())
+    t = torch.from_numpy(a).to(dev)
+    torch.cuda.current_stream(dev).synchronize()                 # the library reads it on its own stream
+    return t
+
+
+class _ChunkPrefetcher:
+    """Streaming feed for storages that deliver a level in many chunks (SampleStorageHDF reads one
+    `collected_values[chunk_slice]` per chunk and reopens the file every time, mlmc/tool/hdf5.py:353-376): a helper thread
+    reads the chunks the estimate is going to miss, in order, up to `depth` ahead of the consumer (double buffering of host
+    chunks), while the main thread uploads the previous chunk and queues its kernels.  Storage reads (h5py, NumPy copies)
+    and the copy to the device both release the GIL, so the two legs really overlap; per chunk the feed costs
+    max(read, upload) instead of their sum.  MLMC_HIP_STREAM_UPLOAD=0 switches it off."""
+
+    def __init__(self, leaf, specs, depth=2):
+        import queue
+        self._leaf = leaf
+        self._specs = list(specs)
+        self._queue = queue.Queue(maxsize=depth)
+        self._stop = False
+        self._thread = threading.Thread(target=self._run, name="mlmc-chunk-reader", daemon=True)
+        self._thread.start()
+
+    @staticmethod
+    def enabled():
+        return os.environ.get("MLMC_HIP_STREAM_UPLOAD", "1") not in ("0", "pinned")
+
+    def _run(self):
+        try:
+            for spec in self._specs:
+                if self._stop:
+                    return
+                self._queue.put((spec, self._leaf.samples(spec), None))
+        except BaseException as e:                                # noqa: BLE001 - handed to the consumer
+            self._queue.put((None, None, e))
+
+    def get(self, spec):
+        """The chunk of `spec`; specs must be asked for in the order they were given."""
+        got, raw, err = self._queue.get()
+        if err is not None:
+            raise err
+        assert got is spec or (got.level_id, got.chunk_id) == (spec.level_id, spec.chunk_id)
+        return raw
+
+    def close(self):
+        self._stop = True
+        try:
+            while True:
+                self._queue.get_nowait()
+        except Exception:
+            pass
 
 
 def _split_fine_coarse(chunk, level_id):
@@ -236,7 +363,7 @@ def _device_tree_enabled():
     return os.environ.get("MLMC_HIP_DEVICE_TREE", "1") != "0"
 
 
-def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache):
+def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache, raw=None):
     """One stored row of one chunk as a device tensor in the storage's own layout: interleaved (fine, coarse) pairs
     [n, 2], or [n, 1] at level 0.  Uploaded once per (storage, chunk, row) and shared by every quantity that reads it."""
     import torch
@@ -249,12 +376,9 @@ def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache):
     if hasattr(storage, "device_row"):                            # samples that already live in HBM (sim/synth_device.py)
         t = storage.device_row(chunk_spec, stored_row)
     else:
-        raw = plan.leaf.samples(chunk_spec)                       # [M_stored, n, 2|1], memoised for this estimate
-        row = np.ascontiguousarray(raw[stored_row], dtype=np.float64)
-        dev = torch.device("cuda", _lib_device())
-        t = torch.from_numpy(row).to(dev)
-        torch.cuda.current_stream(dev).synchronize()    # the library reads it on its own stream
-        _device_cache.uploads += 1
+        if raw is None:
+            raw = plan.leaf.samples(chunk_spec)                   # [M_stored, n, 2|1]
+        t = _upload(raw[stored_row])
     if use_cache:
         _device_cache.put_tensors(key, t, None, owner=owner)
     return t
@@ -284,7 +408,12 @@ def _block_layout(raw, n_rows_read):
     return span, sn, sw
 
 
-def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache):
+# (block key, rows the tree reads) -> (sample stride, side stride, n, width) of a resident block, or None when the chunk is
+# uploaded row by row: a later estimate decides without reading the chunk from the storage again
+_block_meta = {}
+
+
+def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache, raw=None):
     """The whole stored chunk as ONE device buffer in the storage's own [n][2][M] layout (reference Memory storage and
     HDF5 `collected_values`, sample_storage.py:169-184), when the host view allows it: -> (flat device tensor,
     sample stride, side stride, n, width) or None.  One contiguous PCIe copy replaces one strided host gather per
@@ -299,35 +428,49 @@ def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache):
     owner = storage if storage is not None else plan.leaf
     key = ("block", id(owner)) + chunk_key
     item = _device_cache.get(key) if use_cache else None
-    raw = plan.leaf.samples(chunk_spec)                           # [M_stored, n, 2|1] view of the storage
+    if use_cache and (key + ("any",) in _block_meta or key + (len(plan.in_rows),) in _block_meta):
+        return None                                               # known: the chunk goes up row by row (for any / this many rows)
+    if item is not None and key in _block_meta:
+        return (item[0],) + _block_meta[key]                      # a resident block serves every tree
+    if raw is None:
+        raw = plan.leaf.samples(chunk_spec)                       # [M_stored, n, 2|1] view of the storage / fresh read
     layout = _block_layout(raw, len(plan.in_rows))
     if layout is None or layout[0] * 8 > _DeviceChunkCache.budget() // 4:
+        if use_cache:                                             # not a record array at all, or too few of its rows are read
+            intrinsic = layout is not None or _block_layout(raw, raw.shape[0]) is None
+            _block_meta[key + (("any",) if intrinsic else (len(plan.in_rows),))] = None
         return None
     span, sn, sw = layout
     m_total, n, width = raw.shape
     if item is None:
         flat = np.lib.stride_tricks.as_strided(raw, shape=(span,), strides=(8,))
-        dev = torch.device("cuda", _lib_device())
-        t = torch.from_numpy(flat).to(dev)
-        torch.cuda.current_stream(dev).synchronize()             # the library reads it on its own stream
-        _device_cache.uploads += 1
+        t = _upload(flat)
         if use_cache:
             _device_cache.put_tensors(key, t, None, owner=owner)
+            if len(_block_meta) > 65536:
+                _block_meta.clear()
+            _block_meta[key] = (sn, sw, n, width)
     else:
         t = item[0]
     return t, sn, sw, n, width
 
 
-def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache):
-    """Result rows of a lowered quantity for one chunk: fine [M, n'], coarse [M, n'] | None (torch CUDA tensors)."""
-    blk = _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache)
+def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache, raw=None):
+    """Result rows of a lowered quantity for one chunk: fine [M, n'], coarse [M, n'] | None (torch CUDA tensors).
+    raw: the chunk as the storage returned it, when a prefetcher has read it already."""
+    blk = _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache, raw)
     if blk is not None:
         t, sn, sw, n, width = blk
         # without the cache nothing keeps the uploaded block alive past this call: wait for the kernel that reads it
         fine, coarse, _ = plan.evaluate([t[r:] for r in plan.in_rows], has_coarse=(width == 2), n=n, sample_stride=sn,
                                         side_stride=max(sw, 1), sync=not use_cache)
         return fine, coarse
-    rows = [_stored_row_on_device(plan, chunk_spec, chunk_key, r, use_cache) for r in plan.in_rows]
+    storage = getattr(plan.leaf, "_storage", None)
+    if raw is None and not hasattr(storage, "device_row"):
+        owner = storage if storage is not None else plan.leaf
+        if not use_cache or any(("row", id(owner)) + chunk_key + (r,) not in _device_cache._items for r in plan.in_rows):
+            raw = plan.leaf.samples(chunk_spec)                  # ONE read of the chunk for all its rows
+    rows = [_stored_row_on_device(plan, chunk_spec, chunk_key, r, use_cache, raw) for r in plan.in_rows]
     n, width = rows[0].shape
     if n == 0:
         return None
@@ -381,7 +524,7 @@ def _merge_level(pairs):
     return fine, coarse
 
 
-def _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache):
+def _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache, raw=None):
     """Sample rows of `source` for one storage chunk, ready for the accumulators: (fine [M, n], coarse [M, n] | None) as
     torch CUDA tensors (resident: served from / added to the HBM cache) or, when the chunk does not fit the cache budget
     and the tree is evaluated on the host, as NumPy arrays that go through the staging buffer of the C ABI."""
@@ -392,7 +535,7 @@ def _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache):
     if item is not None:
         return item[0], item[1]
     if plan is not None:
-        got = _evaluate_on_device(plan, chunk_spec, key[1:], use_cache)
+        got = _evaluate_on_device(plan, chunk_spec, key[1:], use_cache, raw)
         if got is None:
             import torch
             return torch.empty((plan.n_out, 0), dtype=torch.float64), None
@@ -567,20 +710,37 @@ def _estimate_mean(quantity, group, variance):
             if item is not None:
                 level_done.add(level_id)
                 push_pair(level_id, (item[0], item[1]))
+    specs = [cs for cs in storage_q.chunks() if int(cs.level_id) not in level_done]
+    # chunks of a lowered tree that have to come from the host storage (neither their result rows nor their stored block are
+    # resident): read ahead by a helper thread while this thread uploads and launches (_ChunkPrefetcher)
+    to_read = []
+    if plan is not None and _ChunkPrefetcher.enabled() and not hasattr(getattr(plan.leaf, "_storage", None), "device_row"):
+        have = _device_cache._items
+        for cs in specs:
+            key = _chunk_key(ident, cs, n_collected)
+            resident = use_cache and (key in have or (("block", id(owner)) + key[1:]) in have
+                                      or all((("row", id(owner)) + key[1:] + (r,)) in have for r in plan.in_rows))
+            if not resident:
+                to_read.append(cs)
+    prefetch = _ChunkPrefetcher(plan.leaf, to_read) if len(to_read) > 1 else None
+    waiting = {id(cs) for cs in to_read} if prefetch is not None else set()
     current, pairs, keys = None, [], []
-    for chunk_spec in storage_q.chunks():
-        level_id = int(chunk_spec.level_id)
-        if level_id in level_done:
-            continue
-        if level_id != current:
-            flush_level(current, pairs, keys)
-            current, pairs, keys = level_id, [], []
-        pair = _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache)     # (fine [M, n], coarse | None)
-        if pair is not None and subsample_params is not None and pair[0].shape[-1] > 0:
-            pair = _subsample_on_device(pair, subsample_params[level_id])
-        pairs.append(pair)
-        keys.append(_chunk_key(ident, chunk_spec, n_collected))
-    flush_level(current, pairs, keys)
+    try:
+        for chunk_spec in specs:
+            level_id = int(chunk_spec.level_id)
+            if level_id != current:
+                flush_level(current, pairs, keys)
+                current, pairs, keys = level_id, [], []
+            raw = prefetch.get(chunk_spec) if id(chunk_spec) in waiting else None
+            pair = _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache, raw)     # (fine [M, n], coarse | None)
+            if pair is not None and subsample_params is not None and pair[0].shape[-1] > 0:
+                pair = _subsample_on_device(pair, subsample_params[level_id])
+            pairs.append(pair)
+            keys.append(_chunk_key(ident, chunk_spec, n_collected))
+        flush_level(current, pairs, keys)
+    finally:
+        if prefetch is not None:
+            prefetch.close()
     if acc is None:
         raise Exception("All samples were masked")
     if gathered and not pushed_directly:

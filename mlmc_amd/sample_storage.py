@@ -92,7 +92,12 @@ class Memory(SampleStorage):
     handed over as arrays with `set_level_samples`, which is how large synthetic sets are loaded without Python loops.
     """
 
-    def __init__(self, chunk_size=None):
+    def __init__(self, chunk_size=None, copy_chunks=False):
+        """chunk_size: samples per chunk (None = one chunk per level, the reference's Memory).  copy_chunks: every
+        `sample_pairs_level` call hands out a freshly allocated [n, 2, M] array, as a file-backed storage does
+        (SampleStorageHDF reads `collected_values[chunk_slice]` from the file per chunk, mlmc/tool/hdf5.py:365-376):
+        the stand-in for HDF5 storages in tests and in bench.py's `h2d_inclusive` block (h5py is not part of this image)."""
+        self._copy_chunks = bool(copy_chunks)
         self._failed = {}
         self._results = {}
         self._successful_sample_ids = {}
@@ -182,6 +187,8 @@ class Memory(SampleStorage):
         """-> ndarray [M, chunk size, 2]; level 0 has no coarse samples: [M, chunk size, 1]."""
         results = self._results[int(chunk_spec.level_id)]
         chunk = results if chunk_spec.chunk_slice is None else results[chunk_spec.chunk_slice]
+        if self._copy_chunks:
+            chunk = np.array(chunk, copy=True)
         if chunk.ndim != 3:
             chunk = chunk.reshape(chunk.shape[0], chunk.shape[1], -1)
         if chunk_spec.level_id == 0:

@@ -490,6 +490,106 @@ def test_device_chunk_cache(hip):
     qe.device_cache_clear()
 
 
+def test_streaming_feed_of_a_file_like_storage(hip, monkeypatch):
+    """a storage that hands out every chunk as a fresh [n, 2, M] array (Memory(copy_chunks=True): the read
+    pattern of SampleStorageHDF / LevelGroup.collected, mlmc/tool/hdf5.py:365-376 -- h5py itself is not part of the image,
+    the HDF5 byte format stays "parity unpinned") feeds the estimators (a) through the read-ahead thread (the default feed)
+    and (b) through the pinned staging ring (asynchronous DMA on a copy stream, the library's stream ordered behind it by
+    mlmc_wait_event).  Ragged chunk boundaries, more chunks than buffers, vector and scalar quantities, lowered trees and the
+    host-evaluated path: every estimate equals, bit for bit, the estimate of the same samples from a one-chunk-per-level
+    storage uploaded synchronously; a chunk is read from the storage once."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.sample_storage import Memory
+    steps = [0.5, 0.07, 0.01]
+    levels = level_arrays([40013, 25001, 9000], steps, 4, 17)
+    dom = (-3.7190164854556804, 3.7190164854556804)
+
+    def storage(chunk_size, copy_chunks, records=True):
+        """records: the level arrays are C-contiguous [N, 2, M] records (what an HDF5 read returns: whole chunks go up as one
+        block, k_expr de-interleaves); else component-major, where every stored row already is an [n][2] array (row uploads)"""
+        st = Memory(chunk_size=chunk_size, copy_chunks=copy_chunks)
+        st.save_global_data(result_format=_vec_spec(), level_parameters=[[s] for s in steps])
+        for l, (f, c) in enumerate(levels):
+            if records:
+                st.set_level_samples(l, np.ascontiguousarray(f.T), None if c is None else np.ascontiguousarray(c.T))
+            else:
+                st.set_level_samples(l, f.T, None if c is None else c.T)
+        assert st._results[0].flags.c_contiguous == records
+        return st
+
+    def analyses(st):
+        root = make_root_quantity(st, _vec_spec())['q']
+        scalar = root[1]['0'][0, 0]
+        tree = (root[2]['0'][1, 0] - 0.25) * root[1]['0'][0, 0]
+        host_only = root[2]['0'][0, 0] + 0.5
+        out = []
+        for q, fn in ((scalar, Legendre(12, dom)), (root, Legendre(5, dom)), (tree, Legendre(9, (-20.0, 20.0))), (host_only, Legendre(7, dom))):
+            est = Estimate(q, st, fn)
+            out.append(est.estimate_moments() + est.estimate_covariance())
+        return out
+
+    qe.device_cache_clear()
+    monkeypatch.setenv("MLMC_HIP_STREAM_UPLOAD", "0")
+    want = analyses(storage(None, False))                         # one chunk per level, synchronous uploads
+    qe.device_cache_clear()
+    # (a) read-ahead thread: every chunk is read exactly once per estimate chain that misses it
+    monkeypatch.setenv("MLMC_HIP_STREAM_UPLOAD", "1")
+    for chunk_size, records in ((3001, True), (977, True), (3001, False)):      # 14 + 9 + 3 and 41 + 26 + 10 chunks
+        st = storage(chunk_size, True, records)
+        reads = []
+        inner = st.sample_pairs_level
+        st.sample_pairs_level = lambda spec, inner=inner: reads.append((spec.level_id, spec.chunk_id)) or inner(spec)
+        got = analyses(st)
+        n_chunks = sum(-(-n // chunk_size) for n in (40013, 25001, 9000))
+        # record arrays: all four quantities share ONE upload of every chunk; component-major rows: a chunk is read again
+        # only by a quantity that needs rows nobody has uploaded yet (here: the whole root after the scalar)
+        assert len(set(reads)) == n_chunks and len(reads) == (n_chunks if records else 2 * n_chunks), (chunk_size, records, len(reads))
+        for g, w in zip(got, want):
+            assert all(np.array_equal(a, b) for a, b in zip(g, w)), chunk_size
+        qe.device_cache_clear()
+    # a storage that fails in the reader thread: the error surfaces in the caller
+    st = storage(3001, True)
+    inner = st.sample_pairs_level
+
+    def failing(spec):
+        if spec.level_id == 1 and spec.chunk_id == 2:
+            raise IOError("disk on fire")
+        return inner(spec)
+    st.sample_pairs_level = failing
+    with pytest.raises(IOError, match="disk on fire"):
+        analyses(st)
+    qe.device_cache_clear()
+    # (b) pinned staging ring
+    monkeypatch.setenv("MLMC_HIP_STREAM_UPLOAD", "pinned")
+    for chunk_size in (3001, 977):
+        before = qe._staging.chunks
+        got = analyses(storage(chunk_size, True))
+        assert qe._staging.chunks - before >= sum(-(-n // chunk_size) for n in (40013, 25001, 9000))
+        for g, w in zip(got, want):
+            assert all(np.array_equal(a, b) for a, b in zip(g, w)), chunk_size
+        qe.device_cache_clear()
+    # the host-evaluated path (tree evaluation switched off): chunks are split on the host and staged the same way
+    monkeypatch.setenv("MLMC_HIP_DEVICE_TREE", "0")
+    before = qe._staging.chunks
+    got = analyses(storage(2500, True))
+    assert qe._staging.chunks > before
+    for g, w in zip(got, want):
+        assert all(np.array_equal(a, b) for a, b in zip(g, w))
+    qe.device_cache_clear()
+    # chunks above the staging limit take the one-copy path
+    monkeypatch.setenv("MLMC_HIP_DEVICE_TREE", "1")
+    monkeypatch.setenv("MLMC_HIP_STREAM_CHUNK_MB", "0.001")
+    before = qe._staging.chunks
+    got = analyses(storage(3001, True))
+    assert qe._staging.chunks == before
+    for g, w in zip(got, want):
+        assert all(np.array_equal(a, b) for a, b in zip(g, w))
+    qe.device_cache_clear()
+
+
 # ---- quantity trees evaluated on the device (SURVEY 8(f) row 1) -----------------------------------------------
 def _tree_env(on):
     os.environ["MLMC_HIP_DEVICE_TREE"] = "1" if on else "0"
