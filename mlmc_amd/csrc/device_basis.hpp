@@ -124,6 +124,18 @@ struct TermGen<MLMC_SPLINE> {
         int s = (int)(u * (double)ns);
         s = s < 0 ? 0 : (s > ns - 1 ? ns - 1 : s);
         k = s;
+        if (s >= 2 && s <= ns - 3) {
+            // interior span: none of the knots t_{s+1} .. t_{s+6} that the recurrence touches is a repeated end knot, the four
+            // B-splines are the uniform cubic pieces of the local coordinate v = u ns - s in [0, 1) -- no divisions
+            const double v = u * (double)ns - (double)s;
+            const double v2 = v * v, v3 = v2 * v, om = 1.0 - v;
+            constexpr double sixth = 1.0 / 6.0;
+            n0 = (om * om * om * sixth) * w;
+            n1 = (__builtin_fma(3.0, v3, __builtin_fma(-6.0, v2, 4.0)) * sixth) * w;
+            n2 = (__builtin_fma(-3.0, v3, __builtin_fma(3.0, v2, __builtin_fma(3.0, v, 1.0))) * sixth) * w;
+            n3 = (v3 * sixth) * w;
+            return;
+        }
         const int mu = s + 3;
         double N[4], left[4], right[4];
         N[0] = 1.0;

@@ -615,6 +615,10 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restri
 // ------------------------------------------------------------------------------------------
 constexpr int SPLINE_MAX_R = 512;
 
+// need_sq = 0: the sums of squares are not wanted (mean-only estimate of TransformedMoments over a spline basis, e.g. the
+// orthogonal-moments pass of Estimate.construct_density): half of the LDS atomics -- the kernel's bound, ~3 lane-atomics per
+// cycle and CU for any operand type (tools/ubench_lds_atomics.hip) -- are skipped; the squares' partial rows are zeros.
+template <bool NEED_SQ>
 __global__ __launch_bounds__(ACC_THREADS) void k_spline_accum(BasisParams bp, SegTable tab, int R, double *__restrict__ partials,
                                                              int64_t *__restrict__ pcounts) {
     extern __shared__ double sacc[];              // [4 waves][2][RP], RP = R + 8 (slack for the local 8-window)
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_spline_accum(BasisParams bp, Se
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = gf.k + j;
-                if (r > 0) { atomicAdd(&ws[r], nf[j]); atomicAdd(&wsp[r], nf[j] * nf[j]); }
+                if (r > 0) { atomicAdd(&ws[r], nf[j]); if (NEED_SQ) atomicAdd(&wsp[r], nf[j] * nf[j]); }
             }
             continue;
         }
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_spline_accum(BasisParams bp, Se
             for (int j = 0; j < 4; ++j) {
                 const int r = gf.k + j;
                 const double d = nf[j] - nc[j];
-                if (r > 0) { atomicAdd(&ws[r], d); atomicAdd(&wsp[r], d * d); }
+                if (r > 0) { atomicAdd(&ws[r], d); if (NEED_SQ) atomicAdd(&wsp[r], d * d); }
             }
         } else {
 #pragma unroll
@@ -669,12 +673,12 @@ __global__ __launch_bounds__(ACC_THREADS) void k_spline_accum(BasisParams bp, Se
                 const int r = gf.k + j, jc = j - delta;       // coarse slot holding the same B-spline, if any
                 const double c = jc == 0 ? nc[0] : (jc == 1 ? nc[1] : (jc == 2 ? nc[2] : (jc == 3 ? nc[3] : 0.0)));
                 const double d = nf[j] - c;
-                if (r > 0) { atomicAdd(&ws[r], d); atomicAdd(&wsp[r], d * d); }
+                if (r > 0) { atomicAdd(&ws[r], d); if (NEED_SQ) atomicAdd(&wsp[r], d * d); }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                     // indices touched by the coarse value only
                 const int r = gc.k + j, jf = j + delta;
-                if ((jf < 0 || jf > 3) && r > 0) { atomicAdd(&ws[r], -nc[j]); atomicAdd(&wsp[r], nc[j] * nc[j]); }
+                if ((jf < 0 || jf > 3) && r > 0) { atomicAdd(&ws[r], -nc[j]); if (NEED_SQ) atomicAdd(&wsp[r], nc[j] * nc[j]); }
             }
         }
     }
@@ -901,7 +905,10 @@ int flush_moments(mlmc_accum *a) {
         if (int rc = timing_begin(a)) return rc;
         if (sparse_spline) {
             const size_t lds = sizeof(double) * 4 * 2 * (size_t)(R + 8);
-            hipLaunchKernelGGL(k_spline_accum, dim3(total), dim3(ACC_THREADS), lds, st, bp, tab, R, a->d_partials, a->d_pcounts);
+            if (a->mean_only)   // MOMENTS of TransformedMoments, variances not wanted: the squares feed nothing
+                hipLaunchKernelGGL(k_spline_accum<false>, dim3(total), dim3(ACC_THREADS), lds, st, bp, tab, R, a->d_partials, a->d_pcounts);
+            else
+                hipLaunchKernelGGL(k_spline_accum<true>, dim3(total), dim3(ACC_THREADS), lds, st, bp, tab, R, a->d_partials, a->d_pcounts);
             MLMC_HIP_CHECK(hipGetLastError());
         } else if (split) {
             if (int rc = split_dispatch(1, plain, bp, &tab, total, a->d_partials, a->d_pcounts, nullptr)) return rc;

@@ -7,7 +7,7 @@ import json
 import os
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join("gpurun_out", rnd)
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
@@ -18,7 +18,7 @@ def one(pattern):
     return f[-1] if f else None
 
 
-for cfg in ("c2", "c3", "c6"):
+for cfg in ("c2", "c3", "c6", "c5"):
     f = one(f"trace_{cfg}/*/*_kernel_stats.csv")
     if f:
         rows = list(csv.DictReader(open(f)))
@@ -28,8 +28,8 @@ for cfg in ("c2", "c3", "c6"):
             for r in rows:
                 w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
     summary = {}
-    for kind in ("fetch", "write", "sq"):
-        f = one(f"pmc_{kind}_{cfg}/*/*_counter_collection.csv")
+    for kind in ("fetch", "write", "sq") + (("sq_m64",) if cfg == "c3" else ()):
+        f = one(f"pmc_{kind}_{cfg}/*/*_counter_collection.csv") if kind != "sq_m64" else one("pmc_sq_m64/*/*_counter_collection.csv")
         if not f:
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -42,7 +42,13 @@ for cfg in ("c2", "c3", "c6"):
             meta[k] = dict(grid=r["Grid_Size"], wg=r["Workgroup_Size"], vgpr=r["VGPR_Count"], agpr=r["Accum_VGPR_Count"],
                            sgpr=r["SGPR_Count"], lds=r["LDS_Block_Size"])
         for k, v in agg.items():
-            e = summary.setdefault(k, dict(meta[k]))
+            if kind == "sq_m64":
+                if "k_moments_accum" not in k:
+                    continue
+                k = k + " [stand-alone moments estimates, tools/dev/gpu_split_time_dev.py]"
+                e = summary.setdefault(k, dict(meta[k.split(" [")[0]]))
+            else:
+                e = summary.setdefault(k, dict(meta[k]))
             for c, x in v.items():
                 e[c + "_avg_per_dispatch"] = sum(x) / len(x)
                 e["dispatches_" + kind] = len(x)
