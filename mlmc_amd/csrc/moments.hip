@@ -390,15 +390,23 @@ __global__ __launch_bounds__(ACC_THREADS) void k_moments_accum(BasisParams bp, S
 // 48 < R <= 64 in ONE pass over the samples at two waves per SIMD (Legendre, monomials).
 // A 64-term register tile needs 256 accumulator VGPRs (one wave per SIMD, and a lone wave cannot fill the fp64 pipe); two
 // 32-term passes re-run the first 32 recurrence steps in the second pass (+29 % instructions).  Here the four waves of a
-// workgroup split the TERMS of the same samples: waves 0-1 ("head") own terms [0, 32) -- loads, transform, keep
-// flags, counts, recurrence steps 0..31 -- and hand the state of every recurrence (x, Q_31, Q_30; masked samples: zeros)
-// to waves 2-3 ("tail") through a double-buffered LDS image; the tail continues the same recurrences through terms
-// [32, 64) of the previous trip's samples while the head works on the next trip.  One workgroup barrier per trip (two
+// workgroup split the TERMS of the same samples: waves 0-1 ("head") own terms [0, SPLIT_HEAD) -- loads, transform, keep
+// flags, counts, the first recurrence steps -- and hand the state of every recurrence (x and the last two terms; masked
+// samples: zeros) to waves 2-3 ("tail") through a double-buffered LDS image; the tail continues the same recurrences through
+// terms [SPLIT_HEAD, 64) of the previous trip's samples while the head works on the next trip.  One workgroup barrier per trip (two
 // samples per head lane).  Every recurrence step runs exactly once: the instruction count is that of a single
 // 64-term pass, the occupancy that of the 32-term tile.  Partial rows [2][64] as a 64-term tile would write them.
 // ------------------------------------------------------------------------------------------
 constexpr int SPLIT_LANES = 128;                 // sample lanes per workgroup (head lanes = tail lanes)
-constexpr int SPLIT_HALF = 32;                   // terms per half
+// terms of the head / the tail: the head also loads, transforms and counts (about 50 instructions per trip), the tail only
+// reads the hand-over, so the tail takes four terms more -- 30 / 34 leaves both sides the same instruction count per trip
+// (with 32 / 32 the tail waited at the barrier: SQ_WAIT_ANY 19 % of the wave cycles)
+#ifndef MLMC_SPLIT_HEAD
+#define MLMC_SPLIT_HEAD 30
+#endif
+constexpr int SPLIT_HEAD = MLMC_SPLIT_HEAD;
+constexpr int SPLIT_TAIL = 64 - SPLIT_HEAD;
+constexpr int SPLIT_MAX = SPLIT_HEAD > SPLIT_TAIL ? SPLIT_HEAD : SPLIT_TAIL;
 
 template <int KIND>
 __device__ __forceinline__ void split_export(const TermGen<KIND> &g, double *__restrict__ slot) {
@@ -417,7 +425,7 @@ __device__ __forceinline__ void split_import(TermGen<KIND> &g, const double *__r
 template <int KIND, bool PAIR, bool PLAIN>
 __device__ __forceinline__ void split_head(const BasisParams &bp, const double *__restrict__ fine, const double *__restrict__ coarse,
                                            const uint8_t *__restrict__ mask, int64_t n, int bid, int nb, int n_trips,
-                                           double *__restrict__ hand, double (&s)[SPLIT_HALF], double (&sp)[SPLIT_HALF],
+                                           double *__restrict__ hand, double (&s)[SPLIT_MAX], double (&sp)[SPLIT_MAX],
                                            int &n_keep, int &n_rm) {
     const int64_t T = (int64_t)nb * SPLIT_LANES;
     const int l128 = threadIdx.x & (SPLIT_LANES - 1);
@@ -451,7 +459,7 @@ __device__ __forceinline__ void split_head(const BasisParams &bp, const double *
         gf1.init(k1 ? tf1 : 0.0, w1, bp);
         if (PAIR) { gc0.init(k0 ? tc0 : 0.0, w0, bp); gc1.init(k1 ? tc1 : 0.0, w1, bp); }
 #pragma unroll
-        for (int i = 0; i < SPLIT_HALF; ++i) {
+        for (int i = 0; i < SPLIT_HEAD; ++i) {
             double d0 = gf0.next(i);
             double d1 = gf1.next(i);
             if (PAIR) { d0 -= gc0.next(i); d1 -= gc1.next(i); }
@@ -473,7 +481,7 @@ __device__ __forceinline__ void split_head(const BasisParams &bp, const double *
 
 template <int KIND, bool PAIR>
 __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, const double *__restrict__ hand,
-                                           double (&s)[SPLIT_HALF], double (&sp)[SPLIT_HALF]) {
+                                           double (&s)[SPLIT_MAX], double (&sp)[SPLIT_MAX]) {
     const int l128 = threadIdx.x & (SPLIT_LANES - 1);
     __syncthreads();      // the head's first trip
     for (int k = 0; k < n_trips; ++k) {
@@ -483,10 +491,10 @@ __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, c
         split_import<KIND>(gf1, slot + 3 * SPLIT_LANES);
         if (PAIR) { split_import<KIND>(gc0, slot + 6 * SPLIT_LANES); split_import<KIND>(gc1, slot + 9 * SPLIT_LANES); }
 #pragma unroll
-        for (int i = 0; i < SPLIT_HALF; ++i) {
-            double d0 = gf0.next(SPLIT_HALF + i);
-            double d1 = gf1.next(SPLIT_HALF + i);
-            if (PAIR) { d0 -= gc0.next(SPLIT_HALF + i); d1 -= gc1.next(SPLIT_HALF + i); }
+        for (int i = 0; i < SPLIT_TAIL; ++i) {
+            double d0 = gf0.next(SPLIT_HEAD + i);
+            double d1 = gf1.next(SPLIT_HEAD + i);
+            if (PAIR) { d0 -= gc0.next(SPLIT_HEAD + i); d1 -= gc1.next(SPLIT_HEAD + i); }
             s[i] += d0;
             sp[i] = __builtin_fma(d0, d0, sp[i]);
             s[i] += d1;
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(ACC_THREADS, 2) void k_moments_accum_split(BasisPar
                                                                         double *__restrict__ partials,
                                                                         int64_t *__restrict__ pcounts) {
     __shared__ double hand[2 * 12 * SPLIT_LANES];      // [buffer][recurrence (f0, f1, c0, c1) x (x, Q_31, Q_30)][lane]
-    __shared__ double wsum[4][2 * SPLIT_HALF];
+    __shared__ double wsum[4][2 * SPLIT_MAX];
     __shared__ int ldc[2][2];
     Seg sg = tab.seg[0];
 #pragma unroll
@@ -515,9 +523,9 @@ __global__ __launch_bounds__(ACC_THREADS, 2) void k_moments_accum_split(BasisPar
     const int64_t first = (int64_t)bid * SPLIT_LANES;
     const int n_trips = first < sg.n ? (int)((sg.n - first + T2 - 1) / T2) : 0;
 
-    double s[SPLIT_HALF], sp[SPLIT_HALF];
+    double s[SPLIT_MAX], sp[SPLIT_MAX];
 #pragma unroll
-    for (int i = 0; i < SPLIT_HALF; ++i) { s[i] = 0.0; sp[i] = 0.0; }
+    for (int i = 0; i < SPLIT_MAX; ++i) { s[i] = 0.0; sp[i] = 0.0; }
     int n_keep = 0, n_rm = 0;
     if (wave < 2) {
         if (sg.coarse) split_head<KIND, true, PLAIN>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
@@ -528,19 +536,18 @@ __global__ __launch_bounds__(ACC_THREADS, 2) void k_moments_accum_split(BasisPar
     }
     // ---- block partial: butterfly sums inside every wave (fixed order), then head pair / tail pair added in fixed order ----
 #pragma unroll
-    for (int i = 0; i < SPLIT_HALF; ++i) {
+    for (int i = 0; i < SPLIT_MAX; ++i) {
         const double a = wave_sum(s[i]), b = wave_sum(sp[i]);
-        if (lane == 0) { wsum[wave][i] = a; wsum[wave][SPLIT_HALF + i] = b; }
+        if (lane == 0) { wsum[wave][i] = a; wsum[wave][SPLIT_MAX + i] = b; }
     }
     n_keep = wave_sum_i(n_keep);
     n_rm = wave_sum_i(n_rm);
     if (lane == 0 && wave < 2) { ldc[wave][0] = n_keep; ldc[wave][1] = n_rm; }
     __syncthreads();
-    if (threadIdx.x < 4 * SPLIT_HALF) {
-        const int which = threadIdx.x / (2 * SPLIT_HALF), term = threadIdx.x % (2 * SPLIT_HALF);
-        const int half = term / SPLIT_HALF, i = term % SPLIT_HALF;
-        partials[(int64_t)blockIdx.x * (4 * SPLIT_HALF) + threadIdx.x] =
-            wsum[2 * half][which * SPLIT_HALF + i] + wsum[2 * half + 1][which * SPLIT_HALF + i];
+    if (threadIdx.x < 128) {                      // partial row [which][term], term < 64
+        const int which = threadIdx.x / 64, term = threadIdx.x % 64;
+        const int half = term < SPLIT_HEAD ? 0 : 1, i = half ? term - SPLIT_HEAD : term;
+        partials[(int64_t)blockIdx.x * 128 + threadIdx.x] = wsum[2 * half][which * SPLIT_MAX + i] + wsum[2 * half + 1][which * SPLIT_MAX + i];
     }
     if (threadIdx.x < 2) pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = ldc[0][threadIdx.x] + ldc[1][threadIdx.x];
 }
@@ -833,7 +840,7 @@ int flush_moments(mlmc_accum *a) {
     const int pass_terms = (poly64 && !split) ? 32 : MAX_TERMS_PER_PASS;
     for (int t0 = 0; t0 < (sparse_spline ? 1 : R); t0 += pass_terms) {
         const int n_terms = (R - t0 < pass_terms) ? R - t0 : pass_terms;
-        const int rt_sel = sparse_spline ? R : (split ? 2 * SPLIT_HALF : pick_rt(bp.kind, n_terms, t0));
+        const int rt_sel = sparse_spline ? R : (split ? 64 : pick_rt(bp.kind, n_terms, t0));
         const int width = 2 * rt_sel;
         int per_cu = 4;
         bool plain = bp.kind != MLMC_IDENTITY && !bp.is_log && bp.is_clip;

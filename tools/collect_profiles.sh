@@ -16,7 +16,10 @@ timeout -k 10 300 python3 bench.py --config 6 > $O/bench_c6.json 2> $O/bench_c6.
 timeout -k 10 300 python3 bench.py --config 5 --steps 50 --warmup 10 > $O/bench_c5.json 2> $O/bench_c5.err
 echo "plain benches done" >> $O/progress.txt
 # kernel traces: the default command (BASELINE configs[2] + secondary blocks), configs[1], the tree config
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/trace_c3.log 2>&1
+# config3 = the headline workload alone (its kernel averages are not mixed with the 2e7-sample launches of the north-star block);
+# "default" = the whole default command with the secondary blocks
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/trace_c3.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cd -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/trace_cd.log 2>&1
 echo "trace c3 rc $?" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c2 -- python3 bench.py --config 2 --steps 200 --warmup 50 --no-cpu-baseline > $O/trace_c2.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c6 -- python3 bench.py --config 6 --steps 50 --warmup 10 --no-cpu-baseline > $O/trace_c6.log 2>&1

@@ -18,11 +18,12 @@ def one(pattern):
     return f[-1] if f else None
 
 
-for cfg in ("c2", "c3", "c6", "c5"):
+for cfg in ("c2", "c3", "c6", "c5", "cd"):
     f = one(f"trace_{cfg}/*/*_kernel_stats.csv")
     if f:
         rows = list(csv.DictReader(open(f)))
-        with open(os.path.join(dst, f"{rnd}_kernel_stats_config{cfg[1]}.csv"), "w", newline="") as out:
+        tag = "default_command" if cfg == "cd" else "config" + cfg[1]
+        with open(os.path.join(dst, f"{rnd}_kernel_stats_{tag}.csv"), "w", newline="") as out:
             w = csv.writer(out)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
             for r in rows:
