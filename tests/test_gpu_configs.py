@@ -194,3 +194,31 @@ def test_config4_share_spline_moments_and_maxent(hip, tmp_path):
     # the samples are N(0, 1) (+ a 1 % step perturbation) clipped to the domain: the density follows the normal pdf
     core = np.abs(x) < 2.5
     assert np.max(np.abs(dens[core] - np.exp(-x[core] ** 2 / 2) / np.sqrt(2 * np.pi))) < 2e-2
+
+
+def test_bench_multi_rank_default_is_config3_sharded(hip):
+    """`bench.py --gpus N` (N > 1) as the driver launches it -- torch.distributed.run, one rank per GPU -- rehearsed with two
+    gloo ranks on the one GPU of the box and a reduced total (MLMC_BENCH_TOTAL_PER_LEVEL): BASELINE configs[3] sharded over
+    the ranks, covariance R = 64 through the packed all-reduce, strong scaling, exchange block in the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    total = 3_000_001
+    env = dict(os.environ, MLMC_BENCH_BACKEND="gloo", MLMC_BENCH_DEVICE="0", MLMC_BENCH_TOTAL_PER_LEVEL=str(total))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2 and d["warmup"] == 1
+    assert "configs[3]" in d["config"]["workload"] and d["config"]["estimate"] == "cov" and d["config"]["n_moments"] == 64
+    assert d["config"]["samples_per_level_total"] == total and d["config"]["samples_per_level_per_gpu"] in (total // 2, total - total // 2)
+    assert d["exchange"]["bytes_per_rank"] == 8 * (2 * 5 + 2 * 5 * 64 * 64) and d["exchange"]["allreduce_ms"] > 0
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1.2
+    rc = d["result_check"]
+    assert rc["mean0"] == 1.0 and rc["var0"] == 0.0 and len(rc["n_estimated"]) == 5
+    assert all(0 < r < 0.01 * total for r in rc["n_removed"])                          # both shards were counted
+    assert abs(d["value"] - 5 * total * 64 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]   # whole-job samples x R / time
