@@ -32,8 +32,11 @@ __device__ unsigned long long *g_prof_cov;
 #define MLMC_COV_STAMP(slot)
 #endif
 constexpr int COV_BATCH = 64;
-__host__ __device__ constexpr int cov_batch(int T, bool wide, bool vals) { return (T <= 2 && !wide && !vals) ? 128 : 64; }
-constexpr int COV_LDS_STRIDE = 66;   // doubles per term row: == 2 (mod 32) -> ds_read_b64 fragments hit 32 distinct bank pairs
+// samples per batch: small tiles evaluated from raw samples take 128 sample pairs, or 256 samples at level 0 (one LDS array
+// instead of two, and all four waves evaluate at both kinds of level); everything else 64
+__host__ __device__ constexpr int cov_batch(int T, bool wide, bool vals, bool pair = true) {
+    return (T <= 2 && !wide && !vals) ? (pair ? 128 : 256) : 64;
+}
 
 // MODE 0: G0, G1, G2 (covariance mean + variance);  MODE 1: G = D^T D only (variance of transformed moments);
 // MODE 2: G0 = D^T S only (covariance mean without its variance, e.g. Estimate.construct_density)
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
     constexpr int NT = 16 * T;                 // terms held in LDS
     // samples per batch: 128 for the small tiles evaluated from raw samples (all four waves run recurrences, the
     // barriers and the phase-1 latency are shared by twice the MFMA work), 64 otherwise
-    constexpr int BATCH = cov_batch(T, BI != BJ, VALS);
+    constexpr int BATCH = cov_batch(T, BI != BJ, VALS, PAIR);
     constexpr int STRIDE = BATCH + 2;          // doubles per term row: == 2 (mod 32) -> ds_read_b64 fragments hit 32 distinct bank pairs
     constexpr int NSL = 4 / T;                 // k-slices (waves sharing a row tile split the samples)
     constexpr int NG = (MODE == 0) ? (PAIR ? 3 : 2) : 1;
@@ -339,19 +342,27 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #pragma unroll
         for (int t = 0; t < NS; ++t) accs[g][t] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-    constexpr bool evaluator = W < (PAIR ? 2 : 1);
-    const int samp = PAIR ? (W * 32 + (lane & 31)) : lane;
+    // Batch: 64 sample pairs, or 128 samples at level 0 (one LDS array instead of two: the same 67 KB) -- two evaluator waves
+    // either way (pairs: lane = (sample, fine | coarse); level 0: lane = sample), so the evaluation phase is spread over the
+    // same share of the workgroup at both kinds of level (with 64 samples level 0 kept one wave busy and three waiting).
+    constexpr int BATCH = PAIR ? COV_BATCH : 2 * COV_BATCH;
+    constexpr int STRIDE = BATCH + 2;            // == 2 (mod 32) doubles: conflict-free fragment reads
+    constexpr bool evaluator = W < 2;
+    const int samp = PAIR ? (W * 32 + (lane & 31)) : (W * 64 + lane);
     const bool is_coarse = PAIR && (lane >> 5);
     const double *__restrict__ src = is_coarse ? coarse : fine;
+    // (Measured and not adopted: writing d = f - c and s = f + c instead of f and c -- one half-wave exchange and one add per
+    // term in the evaluator lanes save the four waves of phase 2 eight adds per k-step, but the exchange sits in the
+    // evaluation's dependent chain: +9.6 % on a pair level, same-box A/B, tools/dev/gpu_cov_ab_dev.py.)
     double *__restrict__ dst = is_coarse ? lds_c : lds_f;
     int n_keep = 0, n_rm = 0;
 
-    const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
+    const int64_t n_batches = (n + BATCH - 1) / BATCH;
     int64_t batch = blockIdx.x;
     double xv = 0.0;
     uint8_t mv = 1;
     if (evaluator && batch < n_batches) {
-        int64_t idx = batch * COV_BATCH + samp;
+        int64_t idx = batch * BATCH + samp;
         if (idx < n) { xv = src[idx]; if (mask) mv = mask[idx]; }
     }
 #ifdef MLMC_PROF_COV
@@ -360,7 +371,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #endif
     for (; batch < n_batches; batch += gridDim.x) {
         if (evaluator) {
-            const int64_t idx = batch * COV_BATCH + samp;
+            const int64_t idx = batch * BATCH + samp;
             const bool valid = idx < n;
             bool keep;
             double t = transform_value(bp, xv, keep);
@@ -370,14 +381,14 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
                 keep = keep && (other != 0);
             }
             if (!is_coarse) { n_keep += (int)keep; n_rm += (int)(valid && !keep); }
-            const int64_t nidx = (batch + gridDim.x) * COV_BATCH + samp;
+            const int64_t nidx = (batch + gridDim.x) * BATCH + samp;
             if (nidx < n) { xv = src[nidx]; if (mask) mv = mask[nidx]; }
             TermGen<KIND> g;
             g.init(keep ? t : 0.0, keep ? 1.0 : 0.0, bp);
 #pragma unroll
             for (int i = 0; i < N_EVAL; ++i) {
                 const double q = g.next(i);
-                if (i >= TA) dst[(i - TA) * COV_LDS_STRIDE + samp] = q;
+                if (i >= TA) dst[(i - TA) * STRIDE + samp] = q;
             }
         }
         MLMC_COV_STAMP(0)
@@ -385,17 +396,17 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         MLMC_COV_STAMP(1)
         __builtin_amdgcn_s_setprio(1);   // MFMA phase: issue ahead of the other workgroup's recurrence phase (+1 % MFMA time)
 #pragma unroll
-        for (int ks = 0; ks < COV_BATCH / 4; ++ks) {
+        for (int ks = 0; ks < BATCH / 4; ++ks) {
             const int col = 4 * ks + (lane >> 4);
             double d[4], sm[4];
 #pragma unroll
             for (int J = 0; J < 4; ++J) {
                 const int row = 16 * J + (lane & 15);
-                const double f = lds_f[row * COV_LDS_STRIDE + col];
+                const double f = lds_f[row * STRIDE + col];
                 d[J] = f;
                 sm[J] = f;
                 if (PAIR) {
-                    const double c = lds_c[row * COV_LDS_STRIDE + col];
+                    const double c = lds_c[row * STRIDE + col];
                     d[J] = f - c;
                     sm[J] = f + c;
                 }
@@ -490,12 +501,9 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     if (pcounts) {
         n_keep = wave_sum_i(n_keep);
         n_rm = wave_sum_i(n_rm);
-        if (lane == 0 && W < 2) { ldc[W][0] = n_keep; ldc[W][1] = n_rm; }
+        if (lane == 0 && W < 2) { ldc[W][0] = n_keep; ldc[W][1] = n_rm; }      // both evaluator waves (the coarse lanes carry zeros)
         __syncthreads();
-        if (threadIdx.x < 2) {
-            int v = ldc[0][threadIdx.x] + (PAIR ? ldc[1][threadIdx.x] : 0);
-            pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = v;
-        }
+        if (threadIdx.x < 2) pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = ldc[0][threadIdx.x] + ldc[1][threadIdx.x];
     }
 }
 
@@ -504,8 +512,8 @@ __global__ __launch_bounds__(256, 2) void k_cov_accum_t4(BasisParams bp,
                                                          const double *__restrict__ fine, const double *__restrict__ coarse,
                                                          const uint8_t *__restrict__ mask, int64_t n, int R,
                                                          double *__restrict__ partials, int64_t *__restrict__ pcounts) {
-    __shared__ double lds_f[64 * COV_LDS_STRIDE];
-    __shared__ double lds_c[PAIR ? 64 * COV_LDS_STRIDE : 1];
+    __shared__ double lds_f[64 * ((PAIR ? COV_BATCH : 2 * COV_BATCH) + 2)];       // term-major fine values (level 0: 128 samples)
+    __shared__ double lds_c[PAIR ? 64 * (COV_BATCH + 2) : 1];                      // coarse values
     __shared__ int ldc[2][2];
     (void)R;
     // blockIdx.y = component of a vector quantity (see k_cov_accum): one partial row [3 or 1][64][64] per workgroup
@@ -645,7 +653,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     const int NG = gram_mode == 0 ? 3 : 1;
     const int NB = (R + 63) / 64;          // 64 x 64 output blocks per dimension
     const bool pair = d_c != nullptr;
-    const int64_t bsz = cov_batch(T, false, false);
+    const int64_t bsz = T == 4 ? (pair ? COV_BATCH : 2 * COV_BATCH) : cov_batch(T, false, false, pair);
     const int64_t n_batches = (n + bsz - 1) / bsz;
     const size_t width = (size_t)NG * NT * NT;
     const BasisParams &bp = a->basis->p;

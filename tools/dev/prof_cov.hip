@@ -36,7 +36,7 @@ static void run(const char *name, const BasisParams &bp, const double *f, const 
     for (size_t w = 0; w < (size_t)blocks * 4; ++w)
         for (int k = 0; k < 5; ++k) sum[k] += (double)p[w * 6 + k];
     const double nw = (double)blocks * 4;
-    const int64_t bsz = T == 4 ? COV_BATCH : cov_batch(T, false, false);
+    const int64_t bsz = T == 4 ? (PAIR ? COV_BATCH : 2 * COV_BATCH) : cov_batch(T, false, false, PAIR);
     const double batches_per_wg = (double)((n + bsz - 1) / bsz) / blocks;
     printf("%s: kernel %.3f ms; per wave and batch (cycles): phase1 %.0f  barrier1 %.0f  phase2 %.0f  barrier2 %.0f  total %.0f  (%.1f batches per workgroup)\n",
            name, ms, sum[0] / nw / batches_per_wg, sum[1] / nw / batches_per_wg, sum[2] / nw / batches_per_wg,
