@@ -480,7 +480,8 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
     // the light kernel loses occupancy and the libm kernel spills), as long as the register file of a block stays
     // within 32 KB of LDS
     const int sides = has_coarse ? 2 : 1;
-    const int s_max = 2;
+    // level 0 (8 bytes per sample and row instead of 16): four samples per thread keep as many bytes in flight as two pairs
+    const int s_max = (has_coarse || getenv("MLMC_EXPR_L0_S2")) ? 2 : 4;
     int S = 1;
     while (S < s_max && (size_t)e->n_regs * sides * (2 * S) * X_THREADS * sizeof(double) <= 32768) S *= 2;
     if (const char *force = getenv("MLMC_EXPR_SLOTS")) {   // tuning aid
