@@ -587,8 +587,13 @@ def pdf_solve_timing(fn, L, data, LevelAccumulator, level_stats):
         acc2.close()
         return 1e3 * (t1 - t0), 1e3 * (t2 - t1), ortho, res
 
-    c1, s1, _, _ = chain()
-    c2, s2, ortho, res = chain()
+    gc.collect()
+    gc.disable()      # a generation-2 pass of the cyclic collector (40-80 ms with torch loaded) would land in one of the timings
+    try:
+        c1, s1, _, _ = chain()
+        c2, s2, ortho, res = chain()
+    finally:
+        gc.enable()
     return {"solve_ms": round(s2, 3), "first_solve_ms": round(s1, 3), "estimate_chain_ms": round(c2, 3),
             "first_estimate_chain_ms": round(c1, 3), "n_moments_in": fn.size, "n_moments_orthogonal": int(ortho.size),
             "nit": int(res.nit), "grad_norm": float(res.fun_norm), "success": bool(res.success)}

@@ -38,6 +38,24 @@ __host__ __device__ constexpr int cov_batch(int T, bool wide, bool vals, bool pa
     return (T <= 2 && !wide && !vals) ? (pair ? 128 : 256) : 64;
 }
 
+// Spline moments in phase 1: at most four B-splines (and phi_0 = 1) are non-zero per value, so instead of selecting the
+// value of every term in registers (four compares and selects per term: the evaluation phase of a 128-moment spline
+// covariance took four times that of Legendre) the lane clears its column of the window with plain LDS stores -- which
+// cost the shared fp64 pipe nothing -- and drops the five values in place.  Window = terms [TA, TA + NT).
+template <int NT, int STRIDE, int TA>
+__device__ __forceinline__ void cov_spline_store(const TermGen<MLMC_SPLINE> &g, double *__restrict__ dst, int samp) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) dst[i * STRIDE + samp] = 0.0;
+    if (TA == 0) dst[samp] = g.w;               // phi_0 = 1 (0 for a masked sample)
+    const double nj[4] = {g.n0, g.n1, g.n2, g.n3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int term = g.k + j;               // B_term, term >= 1 (B_0 is replaced by phi_0)
+        const int r = term - TA;
+        if (term >= 1 && r >= 0 && r < NT) dst[r * STRIDE + samp] = nj[j];
+    }
+}
+
 // MODE 0: G0, G1, G2 (covariance mean + variance);  MODE 1: G = D^T D only (variance of transformed moments);
 // MODE 2: G0 = D^T S only (covariance mean without its variance, e.g. Estimate.construct_density)
 // BI, BJ (T = 4 only): the 64 x 64 output block (rows = terms [64 BI, 64 BI + 64), columns = terms [64 BJ, ...)) of
@@ -145,13 +163,18 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
             if (nidx < n) { xv = src[nidx]; if (mask) mv = mask[nidx]; }
             TermGen<KIND> g;
             g.init(keep ? t : 0.0, keep ? 1.0 : 0.0, bp);
-            // all NT terms, fully unrolled (compile-time indices, no branches); rows >= R of the Gram matrices are
-            // never read back
+            if constexpr (KIND == MLMC_SPLINE) {
+                cov_spline_store<NT, STRIDE, TA>(g, dst, samp);
+                if (WIDE) cov_spline_store<NT, STRIDE, TB>(g, dst_b, samp);
+            } else {
+                // all NT terms, fully unrolled (compile-time indices, no branches); rows >= R of the Gram matrices are
+                // never read back
 #pragma unroll
-            for (int i = 0; i < N_EVAL; ++i) {
-                const double q = g.next(i);
-                if (i >= TA && i < TA + NT) dst[(i - TA) * STRIDE + samp] = q;
-                if (WIDE && i >= TB && i < TB + NT) dst_b[(i - TB) * STRIDE + samp] = q;
+                for (int i = 0; i < N_EVAL; ++i) {
+                    const double q = g.next(i);
+                    if (i >= TA && i < TA + NT) dst[(i - TA) * STRIDE + samp] = q;
+                    if (WIDE && i >= TB && i < TB + NT) dst_b[(i - TB) * STRIDE + samp] = q;
+                }
             }
         }
         MLMC_COV_STAMP(0)
@@ -385,10 +408,14 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
             if (nidx < n) { xv = src[nidx]; if (mask) mv = mask[nidx]; }
             TermGen<KIND> g;
             g.init(keep ? t : 0.0, keep ? 1.0 : 0.0, bp);
+            if constexpr (KIND == MLMC_SPLINE) {
+                cov_spline_store<NT, STRIDE, TA>(g, dst, samp);
+            } else {
 #pragma unroll
-            for (int i = 0; i < N_EVAL; ++i) {
-                const double q = g.next(i);
-                if (i >= TA) dst[(i - TA) * STRIDE + samp] = q;
+                for (int i = 0; i < N_EVAL; ++i) {
+                    const double q = g.next(i);
+                    if (i >= TA) dst[(i - TA) * STRIDE + samp] = q;
+                }
             }
         }
         MLMC_COV_STAMP(0)

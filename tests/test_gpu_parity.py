@@ -720,11 +720,20 @@ def test_spline_moments(hip):
         ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(b, x))
         mean, var = _check_against(n, n_rm, s, sp, ref)
         assert mean[0] == 1.0 and var[0] == 0.0
-    b = onp.Basis(onp.SPLINE, 24, dom)
-    lv = [(f[:, :1200], None if c is None else c[:, :1200]) for f, c in levels]
-    n, n_rm, s, sp = _run_accum(Spline(24, dom), lv, mode=LevelAccumulator.COV)
-    ref = onp.estimate_mean(to_chunks(lv), lambda x: onp.covariance_rows(b, x))
-    _check_against(n, n_rm, s, sp, ref)
+    # covariance: every kernel family (16- and 32-term tiles, the 64 x 64 kernel, two term windows), values placed by index
+    from mlmc_amd.engine import level_stats
+    for R, cut in ((10, 1200), (24, 1200), (60, 900), (70, 700)):
+        b = onp.Basis(onp.SPLINE, R, dom)
+        lv = [(f[:, :cut], None if c is None else c[:, :cut]) for f, c in levels]
+        n, n_rm, s, sp = _run_accum(Spline(R, dom), lv, mode=LevelAccumulator.COV)
+        ref = onp.estimate_mean(to_chunks(lv), lambda x: onp.covariance_rows(b, x))
+        assert np.array_equal(n, ref.n_samples) and np.array_equal(n_rm, ref.n_rm_samples)
+        l_means, l_vars = level_stats(n, s, sp)
+        rms = np.sqrt(np.abs(ref.sums_sq) / np.maximum(ref.n_samples[:, None], 1))
+        assert close(l_means, ref.l_means, rms, TOL)
+        # products of splines three knot spans apart are 1e-7 of the level's scale: the parity gate is relative to
+        # max(|b|, scale of the level); such entries carry ~2e-10 relative error in the d / s formulation
+        assert close(l_vars, ref.l_vars, 1e-6 * np.max(ref.l_vars, axis=1, keepdims=True), TOL)
 
 
 def test_covariance_of_transformed_moments(hip):
