@@ -404,9 +404,11 @@ constexpr int SPLIT_LANES = 128;                 // sample lanes per workgroup (
 #ifndef MLMC_SPLIT_HEAD
 #define MLMC_SPLIT_HEAD 30
 #endif
-constexpr int SPLIT_HEAD = MLMC_SPLIT_HEAD;
-constexpr int SPLIT_TAIL = 64 - SPLIT_HEAD;
-constexpr int SPLIT_MAX = SPLIT_HEAD > SPLIT_TAIL ? SPLIT_HEAD : SPLIT_TAIL;
+constexpr int SPLIT_HEAD = MLMC_SPLIT_HEAD;      // of 64 terms (48 < R <= 64)
+// (Measured and not adopted: the same split at 32 terms, 14 / 18, 106 VGPRs = four waves per SIMD, for 24 < R <= 32 -- the
+// hand-over and the barrier per trip cost more than the extra occupancy brings: 0.224 ms against 0.206 ms for the one-pass
+// kernel on BASELINE configs[1], same-box A/B.)
+__host__ __device__ constexpr int split_max(int ht, int tt) { return ht > tt ? ht : tt; }
 
 template <int KIND>
 __device__ __forceinline__ void split_export(const TermGen<KIND> &g, double *__restrict__ slot) {
@@ -422,10 +424,10 @@ __device__ __forceinline__ void split_import(TermGen<KIND> &g, const double *__r
     g.c1 = g.s1 = 0.0;
 }
 
-template <int KIND, bool PAIR, bool PLAIN>
+template <int KIND, bool PAIR, bool PLAIN, int HT, int TT>
 __device__ __forceinline__ void split_head(const BasisParams &bp, const double *__restrict__ fine, const double *__restrict__ coarse,
                                            const uint8_t *__restrict__ mask, int64_t n, int bid, int nb, int n_trips,
-                                           double *__restrict__ hand, double (&s)[SPLIT_MAX], double (&sp)[SPLIT_MAX],
+                                           double *__restrict__ hand, double (&s)[split_max(HT, TT)], double (&sp)[split_max(HT, TT)],
                                            int &n_keep, int &n_rm) {
     const int64_t T = (int64_t)nb * SPLIT_LANES;
     const int l128 = threadIdx.x & (SPLIT_LANES - 1);
@@ -459,7 +461,7 @@ __device__ __forceinline__ void split_head(const BasisParams &bp, const double *
         gf1.init(k1 ? tf1 : 0.0, w1, bp);
         if (PAIR) { gc0.init(k0 ? tc0 : 0.0, w0, bp); gc1.init(k1 ? tc1 : 0.0, w1, bp); }
 #pragma unroll
-        for (int i = 0; i < SPLIT_HEAD; ++i) {
+        for (int i = 0; i < HT; ++i) {
             double d0 = gf0.next(i);
             double d1 = gf1.next(i);
             if (PAIR) { d0 -= gc0.next(i); d1 -= gc1.next(i); }
@@ -479,9 +481,9 @@ __device__ __forceinline__ void split_head(const BasisParams &bp, const double *
     __syncthreads();      // the tail's last trip
 }
 
-template <int KIND, bool PAIR>
+template <int KIND, bool PAIR, int HT, int TT>
 __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, const double *__restrict__ hand,
-                                           double (&s)[SPLIT_MAX], double (&sp)[SPLIT_MAX]) {
+                                           double (&s)[split_max(HT, TT)], double (&sp)[split_max(HT, TT)]) {
     const int l128 = threadIdx.x & (SPLIT_LANES - 1);
     __syncthreads();      // the head's first trip
     for (int k = 0; k < n_trips; ++k) {
@@ -491,10 +493,10 @@ __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, c
         split_import<KIND>(gf1, slot + 3 * SPLIT_LANES);
         if (PAIR) { split_import<KIND>(gc0, slot + 6 * SPLIT_LANES); split_import<KIND>(gc1, slot + 9 * SPLIT_LANES); }
 #pragma unroll
-        for (int i = 0; i < SPLIT_TAIL; ++i) {
-            double d0 = gf0.next(SPLIT_HEAD + i);
-            double d1 = gf1.next(SPLIT_HEAD + i);
-            if (PAIR) { d0 -= gc0.next(SPLIT_HEAD + i); d1 -= gc1.next(SPLIT_HEAD + i); }
+        for (int i = 0; i < TT; ++i) {
+            double d0 = gf0.next(HT + i);
+            double d1 = gf1.next(HT + i);
+            if (PAIR) { d0 -= gc0.next(HT + i); d1 -= gc1.next(HT + i); }
             s[i] += d0;
             sp[i] = __builtin_fma(d0, d0, sp[i]);
             s[i] += d1;
@@ -504,12 +506,14 @@ __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, c
     }
 }
 
-template <int KIND, bool PLAIN>
-__global__ __launch_bounds__(ACC_THREADS, 2) void k_moments_accum_split(BasisParams bp, SegTable tab,
+// HT + TT terms; WPS = waves per SIMD the register allocation is held to
+template <int KIND, bool PLAIN, int HT, int TT, int WPS>
+__global__ __launch_bounds__(ACC_THREADS, WPS) void k_moments_accum_split(BasisParams bp, SegTable tab,
                                                                         double *__restrict__ partials,
                                                                         int64_t *__restrict__ pcounts) {
     __shared__ double hand[2 * 12 * SPLIT_LANES];      // [buffer][recurrence (f0, f1, c0, c1) x (x, Q_31, Q_30)][lane]
-    __shared__ double wsum[4][2 * SPLIT_MAX];
+    constexpr int MAXT = split_max(HT, TT), NTOT = HT + TT;
+    __shared__ double wsum[4][2 * MAXT];
     __shared__ int ldc[2][2];
     Seg sg = tab.seg[0];
 #pragma unroll
@@ -523,31 +527,31 @@ __global__ __launch_bounds__(ACC_THREADS, 2) void k_moments_accum_split(BasisPar
     const int64_t first = (int64_t)bid * SPLIT_LANES;
     const int n_trips = first < sg.n ? (int)((sg.n - first + T2 - 1) / T2) : 0;
 
-    double s[SPLIT_MAX], sp[SPLIT_MAX];
+    double s[MAXT], sp[MAXT];
 #pragma unroll
-    for (int i = 0; i < SPLIT_MAX; ++i) { s[i] = 0.0; sp[i] = 0.0; }
+    for (int i = 0; i < MAXT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
     int n_keep = 0, n_rm = 0;
     if (wave < 2) {
-        if (sg.coarse) split_head<KIND, true, PLAIN>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
-        else split_head<KIND, false, PLAIN>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
+        if (sg.coarse) split_head<KIND, true, PLAIN, HT, TT>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
+        else split_head<KIND, false, PLAIN, HT, TT>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
     } else {
-        if (sg.coarse) split_tail<KIND, true>(bp, n_trips, hand, s, sp);
-        else split_tail<KIND, false>(bp, n_trips, hand, s, sp);
+        if (sg.coarse) split_tail<KIND, true, HT, TT>(bp, n_trips, hand, s, sp);
+        else split_tail<KIND, false, HT, TT>(bp, n_trips, hand, s, sp);
     }
     // ---- block partial: butterfly sums inside every wave (fixed order), then head pair / tail pair added in fixed order ----
 #pragma unroll
-    for (int i = 0; i < SPLIT_MAX; ++i) {
+    for (int i = 0; i < MAXT; ++i) {
         const double a = wave_sum(s[i]), b = wave_sum(sp[i]);
-        if (lane == 0) { wsum[wave][i] = a; wsum[wave][SPLIT_MAX + i] = b; }
+        if (lane == 0) { wsum[wave][i] = a; wsum[wave][MAXT + i] = b; }
     }
     n_keep = wave_sum_i(n_keep);
     n_rm = wave_sum_i(n_rm);
     if (lane == 0 && wave < 2) { ldc[wave][0] = n_keep; ldc[wave][1] = n_rm; }
     __syncthreads();
-    if (threadIdx.x < 128) {                      // partial row [which][term], term < 64
-        const int which = threadIdx.x / 64, term = threadIdx.x % 64;
-        const int half = term < SPLIT_HEAD ? 0 : 1, i = half ? term - SPLIT_HEAD : term;
-        partials[(int64_t)blockIdx.x * 128 + threadIdx.x] = wsum[2 * half][which * SPLIT_MAX + i] + wsum[2 * half + 1][which * SPLIT_MAX + i];
+    if (threadIdx.x < 2 * NTOT) {                 // partial row [which][term], term < NTOT
+        const int which = threadIdx.x / NTOT, term = threadIdx.x % NTOT;
+        const int half = term < HT ? 0 : 1, i = half ? term - HT : term;
+        partials[(int64_t)blockIdx.x * (2 * NTOT) + threadIdx.x] = wsum[2 * half][which * MAXT + i] + wsum[2 * half + 1][which * MAXT + i];
     }
     if (threadIdx.x < 2) pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = ldc[0][threadIdx.x] + ldc[1][threadIdx.x];
 }
@@ -800,23 +804,22 @@ static int accum_dispatch(int op, bool plain, const BasisParams &bp, int rt_sel,
 }
 
 // term-split kernel (48 < R <= 64): op 0: *out = resident blocks per CU; op 1: launch
-template <int KIND, bool PLAIN>
+template <int KIND, bool PLAIN, int HT, int TT, int WPS>
 static int split_go(int op, const BasisParams &bp, const SegTable *tab, int total_blocks, double *partials, int64_t *pcounts, int *out) {
     if (op == 0) {
-        MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(out, (const void *)k_moments_accum_split<KIND, PLAIN>, ACC_THREADS, 0));
+        MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(out, (const void *)k_moments_accum_split<KIND, PLAIN, HT, TT, WPS>, ACC_THREADS, 0));
         return 0;
     }
-    hipLaunchKernelGGL((k_moments_accum_split<KIND, PLAIN>), dim3(total_blocks), dim3(ACC_THREADS), 0, rt().stream, bp, *tab, partials, pcounts);
+    hipLaunchKernelGGL((k_moments_accum_split<KIND, PLAIN, HT, TT, WPS>), dim3(total_blocks), dim3(ACC_THREADS), 0, rt().stream, bp, *tab, partials, pcounts);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 static int split_dispatch(int op, bool plain, const BasisParams &bp, const SegTable *tab, int total_blocks, double *partials,
                           int64_t *pcounts, int *out) {
-    if (bp.kind == MLMC_LEGENDRE)
-        return plain ? split_go<MLMC_LEGENDRE, true>(op, bp, tab, total_blocks, partials, pcounts, out)
-                     : split_go<MLMC_LEGENDRE, false>(op, bp, tab, total_blocks, partials, pcounts, out);
-    return plain ? split_go<MLMC_MONOMIAL, true>(op, bp, tab, total_blocks, partials, pcounts, out)
-                 : split_go<MLMC_MONOMIAL, false>(op, bp, tab, total_blocks, partials, pcounts, out);
+#define MLMC_SPLIT_GO(KIND, P) split_go<KIND, P, SPLIT_HEAD, 64 - SPLIT_HEAD, 2>(op, bp, tab, total_blocks, partials, pcounts, out)
+    if (bp.kind == MLMC_LEGENDRE) return plain ? MLMC_SPLIT_GO(MLMC_LEGENDRE, true) : MLMC_SPLIT_GO(MLMC_LEGENDRE, false);
+    return plain ? MLMC_SPLIT_GO(MLMC_MONOMIAL, true) : MLMC_SPLIT_GO(MLMC_MONOMIAL, false);
+#undef MLMC_SPLIT_GO
 }
 
 // Launch the pending segments of `a` (all passes over the terms), then the grid reduction.
