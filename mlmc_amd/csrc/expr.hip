@@ -9,6 +9,7 @@
 // The register file lives in LDS as [reg][side][thread] (a thread touches only its own column: conflict-free), because
 // registers are indexed by the program.  The program itself is read through uniform (scalar) loads.
 #include "common.hpp"
+#include "expr_jit.hpp"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +23,7 @@ struct mlmc_expr {
     int n_regs = 0, n_in = 0, n_out = 0;
     bool selects = false;
     bool heavy = false;                   // uses a libm-backed operation (k_expr<.., HEAVY = true>)
+    std::shared_ptr<mlmc::ExprJit> jit;   // compiled form of the program, shared by all handles with the same instructions
     mlmc_expr_instr *d_prog = nullptr;
     const double **d_rows = nullptr;      // device copy of the row pointer table
     // scratch of selecting programs: uncompacted rows, flags, block offsets
@@ -220,32 +222,41 @@ __global__ __launch_bounds__(X_THREADS) void k_expr(const mlmc_expr_instr *__res
         }
         // value-producing instructions: the result goes to `prev` and, unless flagged, to its LDS register
         if (op == MLMC_X_LOAD) {
-            const double *__restrict__ row = rows ? rows[ins.a] : tab.p[ins.a];
+            // global address space (global_load, not flat_load) and branch-free: the index is clamped into the row and the value
+            // selected afterwards, so the S loads of an instruction are issued back to back
+            typedef const __attribute__((address_space(1))) double *gptr;
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(1))) d2 *gptr2;
+            const gptr row = (gptr)(rows ? rows[ins.a] : tab.p[ins.a]);
             if (PAIR) {
                 double2 v[S];
                 if (ss == 2 && cs == 1) {           // interleaved (fine, coarse) pairs: one 128-bit load per sample
 #pragma unroll
                     for (int k = 0; k < S; ++k) {   // S independent loads in flight
                         const int64_t i = i0 + (int64_t)k * X_THREADS;
-                        v[k] = i < n ? reinterpret_cast<const double2 *>(row)[i] : make_double2(0.0, 0.0);
+                        const d2 t = ((gptr2)row)[i < n ? i : n - 1];
+                        v[k] = make_double2(t.x, t.y);
                     }
                 } else {                            // a row of a stored [n][2][M] block: strides 2 M (sample), M (side)
 #pragma unroll
                     for (int k = 0; k < S; ++k) {
                         const int64_t i = i0 + (int64_t)k * X_THREADS;
-                        v[k] = i < n ? make_double2(row[i * ss], row[i * ss + cs]) : make_double2(0.0, 0.0);
+                        const int64_t ic = i < n ? i : n - 1;
+                        v[k] = make_double2(row[ic * ss], row[ic * ss + cs]);
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
-                    prev[k] = v[k].x;
-                    prev[(V - S) + k] = v[k].y;
+                    const bool in = i0 + (int64_t)k * X_THREADS < n;
+                    prev[k] = in ? v[k].x : 0.0;
+                    prev[(V - S) + k] = in ? v[k].y : 0.0;
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
                     const int64_t i = i0 + (int64_t)k * X_THREADS;
-                    prev[k] = i < n ? row[i * ss] : 0.0;
+                    const double v = row[(i < n ? i : n - 1) * ss];
+                    prev[k] = i < n ? v : 0.0;
                 }
             }
         } else if (op == MLMC_X_CONST) {
@@ -414,6 +425,7 @@ int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_reg
     e->n_out = n_out_rows;
     e->selects = selects;
     e->heavy = heavy;
+    e->jit = expr_jit_lookup(e->prog, n_regs);
     if (hipMalloc(&e->d_prog, sizeof(mlmc_expr_instr) * n_instr) != hipSuccess ||
         hipMalloc(&e->d_rows, sizeof(double *) * n_in_rows) != hipSuccess ||
         hipHostMalloc(&e->h_total, sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
@@ -513,7 +525,10 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
     do {                                                                                                                   \
         if (S == 4) MLMC_X_LAUNCH(P, 4, H); else if (S == 2) MLMC_X_LAUNCH(P, 2, H); else MLMC_X_LAUNCH(P, 1, H);          \
     } while (0)
-    if (has_coarse) {
+    if (e->jit && expr_jit_ready(*e->jit)) {
+        // the program's own kernel (expr_jit.hip): registers are locals, no LDS, no decode; same rows bit for bit
+        if (int rc = expr_jit_launch(*e->jit, has_coarse != 0, &tab, d_rows, n, sample_stride, side_stride, tf, tc, keep, st)) return rc;
+    } else if (has_coarse) {
         if (e->heavy) MLMC_X_LAUNCH_S(true, true); else MLMC_X_LAUNCH_S(true, false);
     } else {
         if (e->heavy) MLMC_X_LAUNCH_S(false, true); else MLMC_X_LAUNCH_S(false, false);

@@ -2,7 +2,7 @@
 // phase 1 (evaluation), wait at the barrier behind it, phase 2 (MFMA), wait at the barrier behind it.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DMLMC_PROF_COV -I include -I mlmc_amd/csrc
 //        tools/dev/prof_cov.hip mlmc_amd/csrc/api.hip mlmc_amd/csrc/moments.hip mlmc_amd/csrc/maxent.hip mlmc_amd/csrc/select.hip
-//        mlmc_amd/csrc/expr.hip mlmc_amd/csrc/synth.hip -o tools/dev/prof_cov
+//        mlmc_amd/csrc/expr.hip mlmc_amd/csrc/expr_jit.hip mlmc_amd/csrc/synth.hip -o tools/dev/prof_cov
 #include "../../mlmc_amd/csrc/cov.hip"
 #include <algorithm>
 #include <cstdio>
