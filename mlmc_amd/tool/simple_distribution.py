@@ -12,6 +12,32 @@ import ctypes as C
 import numpy as np
 import scipy.integrate as integrate
 import scipy.linalg
+
+
+class _SmallLapack:
+    """Context for the dense LAPACK calls of this module (eigh, rq, eigvalsh on matrices of at most 128 x 128): one BLAS
+    thread.  On a many-core host the threaded BLAS spreads such a call over every core it sees -- on the MI355X boxes of this
+    pool (256 logical cores, a 16-core share per GPU) a 128 x 128 `eigh` that takes 3 ms on one thread took 85-90 ms, thirty
+    times the GPU part of construct_density.  threadpoolctl is optional: without it the calls run as NumPy configures them."""
+    _controller = None
+
+    def __enter__(self):
+        self._ctx = None
+        try:
+            if _SmallLapack._controller is None:
+                from threadpoolctl import ThreadpoolController
+                _SmallLapack._controller = ThreadpoolController()
+            self._ctx = _SmallLapack._controller.limit(limits=1, user_api="blas")
+            self._ctx.__enter__()
+        except Exception:
+            self._ctx = None
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
 from scipy.optimize import OptimizeResult
 
 from .. import _lib
@@ -136,7 +162,8 @@ class SimpleDistribution:
         result.jac = grad
         if self._verbose:
             print("size: {} nits: {} tol: {:5.3g} res: {:5.3g} msg: {}".format(self.approx_size, result.nit, tol, jac_norm, result.message))
-        result.eigvals = np.linalg.eigvalsh(hess)
+        with _SmallLapack():
+            result.eigvals = np.linalg.eigvalsh(hess)
         result.solver_res = result.jac
         # normalisation fix exactly as the reference applies it (:81-86)
         moment_0 = info.moment0
@@ -293,7 +320,8 @@ def construct_ortogonal_moments(moments, cov, tol=None):
     size = moments.size
     centre = np.eye(size)
     centre[:, 0] = -cov[:, 0]
-    ev, evec = np.linalg.eigh(centre @ cov @ centre.T)
+    with _SmallLapack():
+        ev, evec = np.linalg.eigh(centre @ cov @ centre.T)
     if tol is None:
         _, fixed = detect_treshold_slope_change(ev, log=True)
         threshold = int(np.argmax(ev - fixed[0] > 0))
@@ -302,7 +330,8 @@ def construct_ortogonal_moments(moments, cov, tol=None):
     ev_kept = np.flip(ev[threshold:], axis=0)
     evec_kept = np.flip(evec[:, threshold:], axis=1)
     icov_sqrt_t = centre.T @ evec_kept * (1 / np.sqrt(ev_kept))[None, :]
-    r_nm, _ = scipy.linalg.rq(icov_sqrt_t, mode='full')
+    with _SmallLapack():
+        r_nm, _ = scipy.linalg.rq(icov_sqrt_t, mode='full')
     l_mn = r_nm.T
     if l_mn[0, 0] < 0:
         l_mn = -l_mn

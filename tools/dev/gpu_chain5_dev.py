@@ -12,8 +12,10 @@ x = torch.randn(12_500_000, dtype=torch.float64, device="cuda", generator=g)
 f = (x + 0.01 * torch.sqrt(1e-4 + x.abs())).contiguous()
 torch.cuda.synchronize()
 def sync(): _lib.check(_lib.lib().mlmc_synchronize())
+import gc
+gc.collect(); gc.disable()
 for name, fn in (("Spline 128", Spline(128, dom)), ("Legendre 128", Legendre(128, dom)), ("Legendre 64", Legendre(64, dom))):
-    for rep in range(3):
+    for rep in range(6):
         t = [time.perf_counter()]
         acc = LevelAccumulator(fn, 1, LevelAccumulator.COV, mean_only=True); sync(); t.append(time.perf_counter())
         n, _, s, _ = acc.estimate([(0, f, None)], reduce=False); t.append(time.perf_counter())
