@@ -329,16 +329,15 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
 // ------------------------------------------------------------------------------------------
 // Diagonal 64 x 64 blocks (T = 4, one term window): wave-specialised variant that uses the symmetry of
 // G2 = (D.S)^T (D.S) (and, at level 0, of G0 = F^T F and G1 = (F.F)^T (F.F); in MODE 1 of G = D^T D).
-// Only the 10 upper tiles of a symmetric matrix are computed, spread 3 / 3 / 2 / 2 over the four waves; the mirrored
-// tile is written with the partials.  MFMAs per 4 samples and wave: 11 / 11 / 10 / 10 instead of 12 (pair levels),
-// 6 / 6 / 4 / 4 instead of 8 (level 0), 3 / 3 / 2 / 2 instead of 4 (MODE 1).
+// Only the 10 upper tiles of a symmetric matrix are computed, spread 2 / 2 / 3 / 3 over the four waves; the mirrored
+// tile is written with the partials.  MFMAs per 4 samples and wave: 10 / 10 / 11 / 11 instead of 12 (pair levels),
+// 5 / 5 / 5 / 5 instead of 8 (level 0: the second matrix takes the lists in the order 3 / 3 / 2 / 2), 2 / 2 / 3 / 3 instead
+// of 4 (MODE 1).  Waves 0-1 -- the ones with less matrix work -- run the evaluation phase.
 // ------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int sym_n(int w) { return w < 2 ? 3 : 2; }
-__host__ __device__ constexpr int sym_i(int w, int t) { return (w == 3 && t == 1) ? 0 : w; }
-__host__ __device__ constexpr int sym_j(int w, int t) {
-    // w0: (0,0) (0,1) (0,2)   w1: (1,1) (1,2) (1,3)   w2: (2,2) (2,3)   w3: (3,3) (0,3)
-    return (w == 3) ? 3 : w + t;
-}
+// w0: (0,0) (0,1)   w1: (1,1) (1,2)   w2: (2,2) (2,3) (0,2)   w3: (3,3) (0,3) (1,3)
+__host__ __device__ constexpr int sym_n(int w) { return w < 2 ? 2 : 3; }
+__host__ __device__ constexpr int sym_i(int w, int t) { return t == 0 ? w : (w < 2 ? w : (w == 2 ? (t == 1 ? 2 : 0) : (t == 1 ? 0 : 1))); }
+__host__ __device__ constexpr int sym_j(int w, int t) { return t == 0 ? w : (w < 2 ? w + 1 : (w == 2 ? (t == 1 ? 3 : 2) : 3)); }
 
 template <int KIND, bool PAIR, int MODE, int BD, int W>
 __device__ __forceinline__ void cov_t4_body(const BasisParams &bp, 
@@ -350,12 +349,17 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     constexpr int TA = 64 * BD;
     constexpr int N_EVAL = TA + NT;
     constexpr int NS = sym_n(W);
+    // level 0 with variances has TWO symmetric matrices: the second one takes the tile list of wave W + 2, so every wave
+    // issues 2 + 3 = 5 MFMAs per k-step (the same list for both gave 6 / 6 / 4 / 4 and two waves waited at the barrier:
+    // 1.88 -> 1.65 ms per 1e7 samples)
+    constexpr int W1 = (MODE == 0 && !PAIR) ? (W + 2) % 4 : W;
+    constexpr int NS1 = sym_n(W1);
     constexpr int NFULL = (MODE == 0 && PAIR) ? 2 : ((MODE == 2 && PAIR) ? 1 : 0);     // G0 (and G1): full row W
     constexpr int NSYMM = (MODE == 0 && !PAIR) ? 2 : 1;    // symmetric matrices handled through the tile list
     const int lane = threadIdx.x & 63;
 
     v4f64 accf[NFULL > 0 ? NFULL : 1][4];
-    v4f64 accs[NSYMM][NS];
+    v4f64 accs[NSYMM][3];
 #pragma unroll
     for (int g = 0; g < (NFULL > 0 ? NFULL : 1); ++g)
 #pragma unroll
@@ -363,13 +367,16 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #pragma unroll
     for (int g = 0; g < NSYMM; ++g)
 #pragma unroll
-        for (int t = 0; t < NS; ++t) accs[g][t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < 3; ++t) accs[g][t] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
     // Batch: 64 sample pairs, or 128 samples at level 0 (one LDS array instead of two: the same 67 KB) -- two evaluator waves
     // either way (pairs: lane = (sample, fine | coarse); level 0: lane = sample), so the evaluation phase is spread over the
     // same share of the workgroup at both kinds of level (with 64 samples level 0 kept one wave busy and three waiting).
     constexpr int BATCH = PAIR ? COV_BATCH : 2 * COV_BATCH;
     constexpr int STRIDE = BATCH + 2;            // == 2 (mod 32) doubles: conflict-free fragment reads
+    // The evaluators are waves 0-1: they own two tiles of a symmetric matrix where waves 2-3 own three.  (Waves 2-3 as
+    // evaluators: +5 % on a mean-only pair level, same-box A/B.  Which SIMD a wave runs on rotates from workgroup to
+    // workgroup -- HW_ID histogram in tools/dev/prof_cov.hip -- so no assignment balances the SIMDs of a CU exactly.)
     constexpr bool evaluator = W < 2;
     const int samp = PAIR ? (W * 32 + (lane & 31)) : (W * 64 + lane);
     const bool is_coarse = PAIR && (lane >> 5);
@@ -422,6 +429,11 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         __syncthreads();
         MLMC_COV_STAMP(1)
         __builtin_amdgcn_s_setprio(1);   // MFMA phase: issue ahead of the other workgroup's recurrence phase (+1 % MFMA time)
+        // (Measured and not adopted, same-box A/B: explicit register prefetch of the next two k-steps' fragments with the
+        // instructions of two k-steps grouped as reads | vector | matrix by sched_group_barrier: -0.5 % with variances, +13 %
+        // mean-only against the compiler's own interleaving.  A software pipeline with ONE workgroup per CU, two LDS images
+        // and the next batch's recurrences spread over the k-steps of this one -- no evaluation phase, one barrier per batch
+        // -- was 11 % slower at a pair level: a single wave per SIMD leaves every stall of the matrix stream exposed.)
 #pragma unroll
         for (int ks = 0; ks < BATCH / 4; ++ks) {
             const int col = 4 * ks + (lane >> 4);
@@ -455,10 +467,11 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #pragma unroll
                 for (int J = 0; J < 4; ++J) f2[J] = d[J] * d[J];
 #pragma unroll
-                for (int t = 0; t < NS; ++t) {
+                for (int t = 0; t < NS; ++t)
                     accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[sym_i(W, t)], d[sym_j(W, t)], accs[0][t], 0, 0, 0);
-                    accs[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[sym_i(W, t)], f2[sym_j(W, t)], accs[1][t], 0, 0, 0);
-                }
+#pragma unroll
+                for (int t = 0; t < NS1; ++t)
+                    accs[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[sym_i(W1, t)], f2[sym_j(W1, t)], accs[1][t], 0, 0, 0);
             } else if (MODE == 2 && PAIR) {   // covariance mean only: G0 = D^T S, row tile W
 #pragma unroll
                 for (int J = 0; J < 4; ++J)
@@ -479,7 +492,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         unsigned long long *q = g_prof_cov + ((size_t)blockIdx.x * 4 + W) * 6;
         q[0] = prof_acc[0]; q[1] = prof_acc[1]; q[2] = prof_acc[2]; q[3] = prof_acc[3];
         q[4] = __builtin_amdgcn_s_memtime() - prof_t0;
-        q[5] = 0;
+        q[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID: SIMD in bits 5:4
     }
 #endif
 
@@ -511,20 +524,28 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
             if (MODE == 0 && PAIR) {
                 prow[2 * NT * NT + row * NT + col] = accs[0][t][r];
                 if (sym_i(W, t) != sym_j(W, t)) prow[2 * NT * NT + col * NT + row] = accs[0][t][r];
-            } else if (MODE == 0) {   // level 0: G0 = F^T F; G1 = G2 = (F.F)^T (F.F)
+            } else if (MODE == 0) {   // level 0: G0 = F^T F (G1 = G2 below)
                 prow[0 * NT * NT + row * NT + col] = accs[0][t][r];
-                prow[1 * NT * NT + row * NT + col] = accs[1][t][r];
-                prow[2 * NT * NT + row * NT + col] = accs[1][t][r];
-                if (sym_i(W, t) != sym_j(W, t)) {
-                    prow[0 * NT * NT + col * NT + row] = accs[0][t][r];
-                    prow[1 * NT * NT + col * NT + row] = accs[1][t][r];
-                    prow[2 * NT * NT + col * NT + row] = accs[1][t][r];
-                }
+                if (sym_i(W, t) != sym_j(W, t)) prow[0 * NT * NT + col * NT + row] = accs[0][t][r];
             } else {
                 prow[row * NT + col] = accs[0][t][r];
                 if (sym_i(W, t) != sym_j(W, t)) prow[col * NT + row] = accs[0][t][r];
             }
         }
+    if (MODE == 0 && !PAIR) {   // level 0: G1 = G2 = (F.F)^T (F.F), tile list of wave W1
+#pragma unroll
+        for (int t = 0; t < NS1; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * sym_i(W1, t) + r0 + 4 * r, col = 16 * sym_j(W1, t) + c0;
+                prow[1 * NT * NT + row * NT + col] = accs[1][t][r];
+                prow[2 * NT * NT + row * NT + col] = accs[1][t][r];
+                if (sym_i(W1, t) != sym_j(W1, t)) {
+                    prow[1 * NT * NT + col * NT + row] = accs[1][t][r];
+                    prow[2 * NT * NT + col * NT + row] = accs[1][t][r];
+                }
+            }
+    }
     if (pcounts) {
         n_keep = wave_sum_i(n_keep);
         n_rm = wave_sum_i(n_rm);

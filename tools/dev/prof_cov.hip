@@ -41,6 +41,17 @@ static void run(const char *name, const BasisParams &bp, const double *f, const 
     printf("%s: kernel %.3f ms; per wave and batch (cycles): phase1 %.0f  barrier1 %.0f  phase2 %.0f  barrier2 %.0f  total %.0f  (%.1f batches per workgroup)\n",
            name, ms, sum[0] / nw / batches_per_wg, sum[1] / nw / batches_per_wg, sum[2] / nw / batches_per_wg,
            sum[3] / nw / batches_per_wg, sum[4] / nw / batches_per_wg, batches_per_wg);
+    for (int W = 0; W < 4; ++W) {   // per wave index: the same phases, and the SIMD the wave ran on
+        double sw[5] = {0, 0, 0, 0, 0};
+        int simd[4] = {0, 0, 0, 0};
+        for (int b = 0; b < blocks; ++b) {
+            for (int k = 0; k < 5; ++k) sw[k] += (double)p[((size_t)b * 4 + W) * 6 + k];
+            ++simd[(p[((size_t)b * 4 + W) * 6 + 5] >> 4) & 3];
+        }
+        printf("    wave %d: phase1 %.0f  barrier1 %.0f  phase2 %.0f  barrier2 %.0f   SIMD histogram %d %d %d %d\n", W,
+               sw[0] / blocks / batches_per_wg, sw[1] / blocks / batches_per_wg, sw[2] / blocks / batches_per_wg,
+               sw[3] / blocks / batches_per_wg, simd[0], simd[1], simd[2], simd[3]);
+    }
     (void)hipFree(partials);
     (void)hipFree(prof);
 }
