@@ -31,6 +31,33 @@ __device__ unsigned long long *g_prof_cov;
 #else
 #define MLMC_COV_STAMP(slot)
 #endif
+// Issue priorities of the two phases.  The workgroups of a CU take turns: while one runs its matrix phase the other one
+// evaluates, and its dependent recurrence chain gets one issue slot per matrix instruction of the first (the fp64 pipe is one
+// resource).  The evaluating waves must win that slot every time: at the higher priority the evaluation phase is shorter than
+// the other workgroup's matrix phase and the pipe never waits for it (-2.1 % at R = 64, -1.8 % / -5.6 % at R = 32 with / without
+// variances, -3.9 % at R = 16, same-box A/B; round 1 had it the other way round).
+// Fairness between the two workgroups of a CU (64-term kernel): at equal priority the SIMD arbiter serves the older wave first,
+// the workgroup that was dispatched first runs ahead, finishes early (3.0 against 3.6 ms at a pair level of R = 64) and leaves
+// its partner to run alone at one wave per SIMD.  So the matrix phases take turns at priority 1 / 0 in slices of
+// 2^MLMC_COV_SLICE_BITS shader cycles (0.22 ms), by the wave slot on the SIMD (HW_ID.wave_id): both advance at the same average
+// rate and end together (-4.8 % with variances; slices of 2^15 / 2^17 / 2^19 / 2^21: 15.88 / 15.70 / 15.60 / 15.66 ms per
+// configs[2] estimate, same box).  The smaller tiles end together without it and lose 1-4 % with it: constant priority there.
+#ifndef MLMC_COV_PRIO_MFMA
+#define MLMC_COV_PRIO_MFMA 0
+#define MLMC_COV_PRIO_EVAL 2
+#endif
+#ifndef MLMC_COV_SLICE_BITS
+#define MLMC_COV_SLICE_BITS 19
+#endif
+#ifdef MLMC_COV_NO_SLICES
+#define MLMC_COV_MFMA_PRIO(slot, nslots, clock) __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_MFMA)
+#else
+#define MLMC_COV_MFMA_PRIO(slot, nslots, clock)                                                       \
+    do {                                                                                              \
+        if (((unsigned)((clock) >> MLMC_COV_SLICE_BITS)) % (nslots) == (slot)) __builtin_amdgcn_s_setprio(1); \
+        else __builtin_amdgcn_s_setprio(0);                                                           \
+    } while (0)
+#endif
 constexpr int COV_BATCH = 64;
 // samples per batch: small tiles evaluated from raw samples take 128 sample pairs, or 256 samples at level 0 (one LDS array
 // instead of two, and all four waves evaluate at both kinds of level); everything else 64
@@ -129,8 +156,9 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
     }
 #ifdef MLMC_PROF_COV
     unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
-    const unsigned long long prof_t0 = prof_t;
+    const unsigned long long prof_t0 = prof_t, prof_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_EVAL);
     for (; batch < n_batches; batch += gridDim.x) {
         // ---------------- phase 1: moment values of this batch -> LDS ----------------
         if (VALS) {
@@ -181,6 +209,7 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
         __syncthreads();
         MLMC_COV_STAMP(1)
         // ---------------- phase 2: MFMA over the batch ----------------
+        __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_MFMA);
         if constexpr (SLICED) {
             const int rowl = lane & 15;
 #pragma unroll
@@ -220,6 +249,7 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
                         }
                     }
             }
+            __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_EVAL);
             MLMC_COV_STAMP(2)
             __syncthreads();
             MLMC_COV_STAMP(3)
@@ -262,6 +292,7 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_EVAL);
         __syncthreads();
     }
 
@@ -270,7 +301,9 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
         unsigned long long *q = g_prof_cov + ((size_t)blockIdx.x * 4 + wave) * 6;
         q[0] = prof_acc[0]; q[1] = prof_acc[1]; q[2] = prof_acc[2]; q[3] = prof_acc[3];
         q[4] = __builtin_amdgcn_s_memtime() - prof_t0;
-        q[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        q[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffffu) |   // HW_ID: SIMD in bits 5:4
+               ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 16) |      // XCC_ID
+               ((__builtin_amdgcn_s_memrealtime() - prof_r0) << 24);                                           // 100 MHz ticks
     }
 #endif
     // ---------------- write the workgroup's partial tiles ----------------
@@ -397,8 +430,10 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     }
 #ifdef MLMC_PROF_COV
     unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
-    const unsigned long long prof_t0 = prof_t;
+    const unsigned long long prof_t0 = prof_t, prof_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    const unsigned prio_slot = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u) % 2u;   // HW_ID.wave_id
+    __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_EVAL);
     for (; batch < n_batches; batch += gridDim.x) {
         if (evaluator) {
             const int64_t idx = batch * BATCH + samp;
@@ -426,9 +461,10 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
             }
         }
         MLMC_COV_STAMP(0)
+        const unsigned long long prio_clock = __builtin_amdgcn_s_memtime();   // arrives while the wave waits at the barrier
         __syncthreads();
         MLMC_COV_STAMP(1)
-        __builtin_amdgcn_s_setprio(1);   // MFMA phase: issue ahead of the other workgroup's recurrence phase (+1 % MFMA time)
+        MLMC_COV_MFMA_PRIO(prio_slot, 2u, prio_clock);
         // (Measured and not adopted, same-box A/B: explicit register prefetch of the next two k-steps' fragments with the
         // instructions of two k-steps grouped as reads | vector | matrix by sched_group_barrier: -0.5 % with variances, +13 %
         // mean-only against the compiler's own interleaving.  A software pipeline with ONE workgroup per CU, two LDS images
@@ -482,7 +518,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
                     accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[sym_i(W, t)], d[sym_j(W, t)], accs[0][t], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_EVAL);
         MLMC_COV_STAMP(2)
         __syncthreads();
         MLMC_COV_STAMP(3)
@@ -492,7 +528,9 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         unsigned long long *q = g_prof_cov + ((size_t)blockIdx.x * 4 + W) * 6;
         q[0] = prof_acc[0]; q[1] = prof_acc[1]; q[2] = prof_acc[2]; q[3] = prof_acc[3];
         q[4] = __builtin_amdgcn_s_memtime() - prof_t0;
-        q[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID: SIMD in bits 5:4
+        q[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffffu) |   // HW_ID: SIMD in bits 5:4
+               ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 16) |      // XCC_ID
+               ((__builtin_amdgcn_s_memrealtime() - prof_r0) << 24);                                           // 100 MHz ticks
     }
 #endif
 

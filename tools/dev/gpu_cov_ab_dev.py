@@ -31,6 +31,8 @@ for mean_only in (False, True):
 print("%%.4f %%.4f %%.4f %%.4f" %% tuple(out))
 ''' % root
 libs = {"new": os.path.join(root, "mlmc_amd", "libmlmc_hip.so"), "old": os.path.join(root, "tools", "dev", "libmlmc_covold.so")}
+if os.environ.get("LIBS"):   # LIBS="name=path,name=path": other variants (paths relative to the repository root)
+    libs = {kv.split("=")[0]: os.path.join(root, kv.split("=")[1]) for kv in os.environ["LIBS"].split(",")}
 res = {k: [] for k in libs}
 for rnd in range(3):
     for name, lib in libs.items():

@@ -41,6 +41,29 @@ static void run(const char *name, const BasisParams &bp, const double *f, const 
     printf("%s: kernel %.3f ms; per wave and batch (cycles): phase1 %.0f  barrier1 %.0f  phase2 %.0f  barrier2 %.0f  total %.0f  (%.1f batches per workgroup)\n",
            name, ms, sum[0] / nw / batches_per_wg, sum[1] / nw / batches_per_wg, sum[2] / nw / batches_per_wg,
            sum[3] / nw / batches_per_wg, sum[4] / nw / batches_per_wg, batches_per_wg);
+    {   // spread of the waves' total cycles: workgroups that finish early leave their CU partner running alone
+        unsigned long long lo = ~0ull, hi = 0;
+        for (size_t w = 0; w < (size_t)blocks * 4; ++w) { lo = std::min(lo, p[w * 6 + 4]); hi = std::max(hi, p[w * 6 + 4]); }
+        printf("    cycles per wave: min %.3f M  max %.3f M  -> shader clock >= %.2f GHz over the kernel's %.3f ms\n", lo * 1e-6, hi * 1e-6,
+               hi * 1e-6 / ms, ms);
+        {   // by wave slot (HW_ID.wave_id): how many waves, their mean wall time
+            double sum[16] = {0}; int cnt[16] = {0};
+            for (size_t w = 0; w < (size_t)blocks * 4; ++w) { const int id = (int)(p[w * 6 + 5] & 15); sum[id] += (double)(p[w * 6 + 5] >> 24) * 0.01; ++cnt[id]; }
+            printf("      wave slot: waves, mean wall us:");
+            for (int i = 0; i < 16; ++i) if (cnt[i]) printf("  [%d] %d %.0f", i, cnt[i], sum[i] / cnt[i]);
+            printf("\n");
+        }
+        // per XCD: wall time of its waves (100 MHz ticks) and their clock
+        for (int x = 0; x < 8; ++x) {
+            double tl = 1e30, th = 0, cl = 1e30, ch = 0; int cnt = 0;
+            for (size_t w = 0; w < (size_t)blocks * 4; ++w) {
+                if ((int)((p[w * 6 + 5] >> 16) & 15) != x) continue;
+                const double us = (double)(p[w * 6 + 5] >> 24) * 0.01, ghz = (double)p[w * 6 + 4] / (us * 1e3);
+                tl = std::min(tl, us); th = std::max(th, us); cl = std::min(cl, ghz); ch = std::max(ch, ghz); ++cnt;
+            }
+            if (cnt) printf("      XCD %d: %4d waves, wall %.0f .. %.0f us, clock %.3f .. %.3f GHz\n", x, cnt, tl, th, cl, ch);
+        }
+    }
     for (int W = 0; W < 4; ++W) {   // per wave index: the same phases, and the SIMD the wave ran on
         double sw[5] = {0, 0, 0, 0, 0};
         int simd[4] = {0, 0, 0, 0};
