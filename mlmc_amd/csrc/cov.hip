@@ -469,7 +469,10 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         // instructions of two k-steps grouped as reads | vector | matrix by sched_group_barrier: -0.5 % with variances, +13 %
         // mean-only against the compiler's own interleaving.  A software pipeline with ONE workgroup per CU, two LDS images
         // and the next batch's recurrences spread over the k-steps of this one -- no evaluation phase, one barrier per batch
-        // -- was 11 % slower at a pair level: a single wave per SIMD leaves every stall of the matrix stream exposed.)
+        // -- was 11 % slower at a pair level: a single wave per SIMD leaves every stall of the matrix stream exposed.  The same
+        // pipeline with batches of 32 pairs, two 35 KB images per workgroup, two workgroups per CU and one evaluator wave
+        // (9 / 11 / 11 / 11 MFMAs per k-step): +10 % with variances, +17 % mean-only -- the evaluator wave's in-order stream
+        // of dependent recurrence steps between its matrix instructions paces the whole workgroup.)
 #pragma unroll
         for (int ks = 0; ks < BATCH / 4; ++ks) {
             const int col = 4 * ks + (lane >> 4);

@@ -32,11 +32,15 @@ print("%%.4f %%.4f %%.4f %%.4f" %% tuple(out))
 ''' % root
 libs = {"new": os.path.join(root, "mlmc_amd", "libmlmc_hip.so"), "old": os.path.join(root, "tools", "dev", "libmlmc_covold.so")}
 if os.environ.get("LIBS"):   # LIBS="name=path,name=path": other variants (paths relative to the repository root)
-    libs = {kv.split("=")[0]: os.path.join(root, kv.split("=")[1]) for kv in os.environ["LIBS"].split(",")}
+    libs = {kv.split("=", 1)[0]: os.path.join(root, kv.split("=", 1)[1]) for kv in os.environ["LIBS"].split(",")}
 res = {k: [] for k in libs}
 for rnd in range(3):
     for name, lib in libs.items():
-        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MLMC_HIP_LIB=lib), capture_output=True, text=True, timeout=300)
+        extra = {}
+        if "@" in lib:   # "path@VAR=VAL": the same library under another environment switch
+            lib, kv = lib.split("@")
+            extra = dict([kv.split("=")])
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MLMC_HIP_LIB=lib, **extra), capture_output=True, text=True, timeout=300)
         if out.returncode != 0:
             print(name, "FAILED", out.stderr[-500:]); continue
         res[name].append([float(v) for v in out.stdout.strip().splitlines()[-1].split()])
