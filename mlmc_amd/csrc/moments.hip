@@ -409,6 +409,22 @@ constexpr int SPLIT_HEAD = MLMC_SPLIT_HEAD;      // of 64 terms (48 < R <= 64)
 // hand-over and the barrier per trip cost more than the extra occupancy brings: 0.224 ms against 0.206 ms for the one-pass
 // kernel on BASELINE configs[1], same-box A/B.)
 __host__ __device__ constexpr int split_max(int ht, int tt) { return ht > tt ? ht : tt; }
+// the two workgroups of a CU take turns at the higher issue priority, like the waves of k_moments_accum (see accum_samples)
+#ifdef MLMC_SPLIT_NO_PRIO
+#define MLMC_SPLIT_PRIO_INIT
+#define MLMC_SPLIT_PRIO_TRIP
+#else
+#ifndef MLMC_SPLIT_PRIO_BITS
+#define MLMC_SPLIT_PRIO_BITS 16
+#endif
+#define MLMC_SPLIT_PRIO_INIT                                                                                              \
+    const unsigned prio_phase = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u) & 1u; /* HW_ID.wave_id */     \
+    unsigned long long prio_clock = __builtin_amdgcn_s_memtime();
+#define MLMC_SPLIT_PRIO_TRIP                                                                                              \
+    if ((((unsigned)(prio_clock >> MLMC_SPLIT_PRIO_BITS)) & 1u) == prio_phase) __builtin_amdgcn_s_setprio(2);             \
+    else __builtin_amdgcn_s_setprio(0);                                                                                   \
+    prio_clock = __builtin_amdgcn_s_memtime();
+#endif
 
 template <int KIND>
 __device__ __forceinline__ void split_export(const TermGen<KIND> &g, double *__restrict__ slot) {
@@ -436,7 +452,9 @@ __device__ __forceinline__ void split_head(const BasisParams &bp, const double *
     uint8_t m0 = 1, m1 = 1;
     if (i0 < n) { f0 = fine[i0]; if (PAIR) c0 = coarse[i0]; if (!PLAIN && mask) m0 = mask[i0]; }
     if (i1 < n) { f1 = fine[i1]; if (PAIR) c1 = coarse[i1]; if (!PLAIN && mask) m1 = mask[i1]; }
+    MLMC_SPLIT_PRIO_INIT
     for (int k = 0; k < n_trips; ++k) {
+        MLMC_SPLIT_PRIO_TRIP
         const bool v0 = i0 < n, v1 = i1 < n;
         const double xf0 = f0, xf1 = f1, xc0 = c0, xc1 = c1;
         const uint8_t mm0 = m0, mm1 = m1;
@@ -486,7 +504,9 @@ __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, c
                                            double (&s)[split_max(HT, TT)], double (&sp)[split_max(HT, TT)]) {
     const int l128 = threadIdx.x & (SPLIT_LANES - 1);
     __syncthreads();      // the head's first trip
+    MLMC_SPLIT_PRIO_INIT
     for (int k = 0; k < n_trips; ++k) {
+        MLMC_SPLIT_PRIO_TRIP
         const double *__restrict__ slot = hand + (size_t)(k & 1) * (12 * SPLIT_LANES) + l128;
         TermGen<KIND> gf0, gf1, gc0, gc1;
         split_import<KIND>(gf0, slot);

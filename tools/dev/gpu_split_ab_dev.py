@@ -24,6 +24,8 @@ print("%%.4f" %% (ms / 200))
 ''' % root
 libs = {"30/34 (shipped)": os.path.join(root, "mlmc_amd", "libmlmc_hip.so"), "32/32": os.path.join(root, "tools", "dev", "libmlmc_split32.so"),
         "28/36": os.path.join(root, "tools", "dev", "libmlmc_split28.so")}
+if os.environ.get("LIBS"):   # LIBS="name=path,name=path" (paths relative to the repository root)
+    libs = {kv.split("=", 1)[0]: os.path.join(root, kv.split("=", 1)[1]) for kv in os.environ["LIBS"].split(",")}
 res = {k: [] for k in libs}
 for rnd in range(3):
     for name, lib in libs.items():
