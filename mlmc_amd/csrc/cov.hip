@@ -31,34 +31,53 @@ __device__ unsigned long long *g_prof_cov;
 #else
 #define MLMC_COV_STAMP(slot)
 #endif
-// Issue priorities of the two phases.  The workgroups of a CU take turns: while one runs its matrix phase the other one
-// evaluates, and its dependent recurrence chain gets one issue slot per matrix instruction of the first (the fp64 pipe is one
-// resource).  The evaluating waves must win that slot every time: at the higher priority the evaluation phase is shorter than
-// the other workgroup's matrix phase and the pipe never waits for it (-2.1 % at R = 64, -1.8 % / -5.6 % at R = 32 with / without
-// variances, -3.9 % at R = 16, same-box A/B; round 1 had it the other way round).
-// Fairness between the two workgroups of a CU (64-term kernel): at equal priority the SIMD arbiter serves the older wave first,
-// the workgroup that was dispatched first runs ahead, finishes early (3.0 against 3.6 ms at a pair level of R = 64) and leaves
-// its partner to run alone at one wave per SIMD.  So the matrix phases take turns at priority 1 / 0 in slices of
-// 2^MLMC_COV_SLICE_BITS shader cycles (0.22 ms), by the wave slot on the SIMD (HW_ID.wave_id): both advance at the same average
-// rate and end together (-4.8 % with variances; slices of 2^15 / 2^17 / 2^19 / 2^21: 15.88 / 15.70 / 15.60 / 15.66 ms per
-// configs[2] estimate, same box).  The smaller tiles end together without it and lose 1-4 % with it: constant priority there.
+// Issue priorities of the two phases.  The workgroups of a CU take turns: while some run their matrix phase another one
+// evaluates, and below the matrix instructions its dependent recurrence chain would get one issue slot per matrix instruction
+// (the fp64 pipe is one resource).  At the higher priority the evaluation phase takes a third of that time and the pipe never
+// waits for it (-2.1 % at R = 64, -1.8 % / -5.6 % at R = 32 with / without variances, -3.9 % at R = 16, same-box A/B; round 1
+// had it the other way round).
+// Fairness between the workgroups of a CU (64-term kernel): at equal priority the SIMD arbiter serves the older wave first,
+// the workgroup that was dispatched first runs ahead, finishes early (two per CU: 3.0 against 3.6 ms at a pair level; four
+// per CU: 2.5 / 2.9 / 3.2 / 3.5 ms) and leaves the others to run with fewer waves per SIMD.  So the matrix phases change their
+// priority in slices of 2^MLMC_COV_SLICE_BITS shader cycles by the workgroup's rank on its CU:
+//   with variances at a pair level (RANKS): the ranks rotate through the priorities 0 .. 3, evaluation at 3;
+//   otherwise: one workgroup at 1, the others at 0, evaluation at 2 (those kernels end together anyway; rotating ranks cost
+//   them 1-2 %).
+// Two per CU: -4.8 % (slices of 2^15 / 2^17 / 2^19 / 2^21: 15.88 / 15.70 / 15.60 / 15.66 ms per configs[2] estimate); four per
+// CU with rotating ranks: a further -1.7 %.  The smaller tiles end together without slices and lose 1-4 % with them.
 #ifndef MLMC_COV_PRIO_MFMA
 #define MLMC_COV_PRIO_MFMA 0
 #define MLMC_COV_PRIO_EVAL 2
 #endif
 #ifndef MLMC_COV_SLICE_BITS
-#define MLMC_COV_SLICE_BITS 19
+#define MLMC_COV_SLICE_BITS 17
 #endif
-#ifdef MLMC_COV_NO_SLICES
-#define MLMC_COV_MFMA_PRIO(slot, nslots, clock) __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_MFMA)
-#else
-#define MLMC_COV_MFMA_PRIO(slot, nslots, clock)                                                       \
+#define MLMC_COV_MFMA_PRIO(ranks, slot, nslots, clock)                                                \
     do {                                                                                              \
-        if (((unsigned)((clock) >> MLMC_COV_SLICE_BITS)) % (nslots) == (slot)) __builtin_amdgcn_s_setprio(1); \
-        else __builtin_amdgcn_s_setprio(0);                                                           \
+        const unsigned rank_ = (((unsigned)((clock) >> MLMC_COV_SLICE_BITS)) + (slot)) % (nslots);    \
+        if (rank_ == 0) __builtin_amdgcn_s_setprio((ranks) ? 0 : 1);                                  \
+        else if (rank_ == 1) __builtin_amdgcn_s_setprio((ranks) ? 1 : 0);                             \
+        else if (rank_ == 2) __builtin_amdgcn_s_setprio((ranks) ? 2 : 0);                             \
+        else __builtin_amdgcn_s_setprio((ranks) ? 3 : 0);                                             \
     } while (0)
-#endif
+#define MLMC_COV_EVAL_PRIO(ranks)                                                                     \
+    do {                                                                                              \
+        if (ranks) __builtin_amdgcn_s_setprio(3);                                                     \
+        else __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_EVAL);                                          \
+    } while (0)
 constexpr int COV_BATCH = 64;
+#ifndef MLMC_COV_T4_ONE_LIST
+#define MLMC_COV_T4_ONE_LIST 1
+#endif
+// 64-term kernel: batches of 32 pairs (35 KB of LDS) and FOUR workgroups per CU -- against 64 pairs and two workgroups: -1 %
+// with variances, -8 % mean-only, -3.5 % at level 0 (same-box A/B): four waves per SIMD cover each other's barriers and
+// evaluation phases better than two, at 92 VGPRs the register file allows five.
+#ifndef MLMC_COV_T4_BATCH
+#define MLMC_COV_T4_BATCH 32
+#define MLMC_COV_T4_WGS 4
+#endif
+constexpr int COV_T4_BATCH = MLMC_COV_T4_BATCH;   // pairs per batch of the 64-term kernel (level 0: twice as many samples)
+constexpr int COV_T4_WGS = MLMC_COV_T4_WGS;       // its workgroups per CU
 // samples per batch: small tiles evaluated from raw samples take 128 sample pairs, or 256 samples at level 0 (one LDS array
 // instead of two, and all four waves evaluate at both kinds of level); everything else 64
 __host__ __device__ constexpr int cov_batch(int T, bool wide, bool vals, bool pair = true) {
@@ -371,6 +390,14 @@ __global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisPara
 __host__ __device__ constexpr int sym_n(int w) { return w < 2 ? 2 : 3; }
 __host__ __device__ constexpr int sym_i(int w, int t) { return t == 0 ? w : (w < 2 ? w : (w == 2 ? (t == 1 ? 2 : 0) : (t == 1 ? 0 : 1))); }
 __host__ __device__ constexpr int sym_j(int w, int t) { return t == 0 ? w : (w < 2 ? w + 1 : (w == 2 ? (t == 1 ? 3 : 2) : 3)); }
+// One evaluator wave (32-pair batches): it takes a single tile, w0: (0,0)   w1: (1,1) (1,2) (0,1)   w2: (2,2) (2,3) (0,2)
+// w3: (3,3) (0,3) (1,3) -- 9 / 11 / 11 / 11 MFMAs per k-step at a pair level, the evaluation goes to the wave with 9.
+__host__ __device__ constexpr int psym_n(int w) { return w == 0 ? 1 : 3; }
+__host__ __device__ constexpr int psym_i(int w, int t) { return t == 0 ? w : (w == 1 ? (t == 1 ? 1 : 0) : (w == 2 ? (t == 1 ? 2 : 0) : (t == 1 ? 0 : 1))); }
+__host__ __device__ constexpr int psym_j(int w, int t) { return t == 0 ? w : (w == 1 ? (t == 1 ? 2 : 1) : (w == 2 ? (t == 1 ? 3 : 2) : 3)); }
+__host__ __device__ constexpr int xsym_n(bool one, int w) { return one ? psym_n(w) : sym_n(w); }
+__host__ __device__ constexpr int xsym_i(bool one, int w, int t) { return one ? psym_i(w, t) : sym_i(w, t); }
+__host__ __device__ constexpr int xsym_j(bool one, int w, int t) { return one ? psym_j(w, t) : sym_j(w, t); }
 
 template <int KIND, bool PAIR, int MODE, int BD, int W>
 __device__ __forceinline__ void cov_t4_body(const BasisParams &bp, 
@@ -381,7 +408,8 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     constexpr int NT = 64;
     constexpr int TA = 64 * BD;
     constexpr int N_EVAL = TA + NT;
-    constexpr int NS = sym_n(W);
+    constexpr bool ONE = PAIR && MLMC_COV_T4_ONE_LIST && COV_T4_BATCH == 32;   // tile lists for a single evaluator wave
+    constexpr int NS = xsym_n(ONE, W);
     // level 0 with variances has TWO symmetric matrices: the second one takes the tile list of wave W + 2, so every wave
     // issues 2 + 3 = 5 MFMAs per k-step (the same list for both gave 6 / 6 / 4 / 4 and two waves waited at the barrier:
     // 1.88 -> 1.65 ms per 1e7 samples)
@@ -402,15 +430,15 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #pragma unroll
         for (int t = 0; t < 3; ++t) accs[g][t] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
-    // Batch: 64 sample pairs, or 128 samples at level 0 (one LDS array instead of two: the same 67 KB) -- two evaluator waves
-    // either way (pairs: lane = (sample, fine | coarse); level 0: lane = sample), so the evaluation phase is spread over the
-    // same share of the workgroup at both kinds of level (with 64 samples level 0 kept one wave busy and three waiting).
-    constexpr int BATCH = PAIR ? COV_BATCH : 2 * COV_BATCH;
+    // Batch: COV_T4_BATCH sample pairs, or twice as many samples at level 0 (one LDS array instead of two: the same bytes) --
+    // COV_T4_BATCH / 32 evaluator waves either way (pairs: lane = (sample, fine | coarse); level 0: lane = sample), so the
+    // evaluation phase is spread over the same share of the workgroup at both kinds of level.
+    constexpr int BATCH = PAIR ? COV_T4_BATCH : 2 * COV_T4_BATCH;
     constexpr int STRIDE = BATCH + 2;            // == 2 (mod 32) doubles: conflict-free fragment reads
-    // The evaluators are waves 0-1: they own two tiles of a symmetric matrix where waves 2-3 own three.  (Waves 2-3 as
-    // evaluators: +5 % on a mean-only pair level, same-box A/B.  Which SIMD a wave runs on rotates from workgroup to
+    // The evaluators are the first waves: they own fewer tiles of a symmetric matrix than the others.  (Waves 2-3 as
+    // evaluators of 64-pair batches: +5 % on a mean-only pair level, same-box A/B.  Which SIMD a wave runs on rotates from workgroup to
     // workgroup -- HW_ID histogram in tools/dev/prof_cov.hip -- so no assignment balances the SIMDs of a CU exactly.)
-    constexpr bool evaluator = W < 2;
+    constexpr bool evaluator = W < COV_T4_BATCH / 32;
     const int samp = PAIR ? (W * 32 + (lane & 31)) : (W * 64 + lane);
     const bool is_coarse = PAIR && (lane >> 5);
     const double *__restrict__ src = is_coarse ? coarse : fine;
@@ -432,8 +460,13 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
     const unsigned long long prof_t0 = prof_t, prof_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const unsigned prio_slot = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u) % 2u;   // HW_ID.wave_id
-    __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_EVAL);
+    // rank of the workgroup among the COV_T4_WGS that share its CU: the dispatcher deals the workgroups of a full grid
+    // (launch_cov_accum: COV_T4_WGS per CU) round-robin over the CUs, so the partners of block b are b + n_cu, b + 2 n_cu, ...
+    // (checked with HW_ID in tools/dev/prof_cov.hip); all four waves of a workgroup share the rank
+    constexpr bool RANKS = MODE == 0 && PAIR;      // rotating priorities (see MLMC_COV_MFMA_PRIO)
+    const unsigned per_round = gridDim.x >= (unsigned)COV_T4_WGS ? gridDim.x / (unsigned)COV_T4_WGS : 1u;
+    const unsigned prio_slot = (blockIdx.x / per_round) % (unsigned)COV_T4_WGS;
+    MLMC_COV_EVAL_PRIO(RANKS);
     for (; batch < n_batches; batch += gridDim.x) {
         if (evaluator) {
             const int64_t idx = batch * BATCH + samp;
@@ -464,7 +497,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         const unsigned long long prio_clock = __builtin_amdgcn_s_memtime();   // arrives while the wave waits at the barrier
         __syncthreads();
         MLMC_COV_STAMP(1)
-        MLMC_COV_MFMA_PRIO(prio_slot, 2u, prio_clock);
+        MLMC_COV_MFMA_PRIO(RANKS, prio_slot, (unsigned)COV_T4_WGS, prio_clock);
         // (Measured and not adopted, same-box A/B: explicit register prefetch of the next two k-steps' fragments with the
         // instructions of two k-steps grouped as reads | vector | matrix by sched_group_barrier: -0.5 % with variances, +13 %
         // mean-only against the compiler's own interleaving.  A software pipeline with ONE workgroup per CU, two LDS images
@@ -500,14 +533,14 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
                 }
 #pragma unroll
                 for (int t = 0; t < NS; ++t)
-                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ds[sym_i(W, t)], ds[sym_j(W, t)], accs[0][t], 0, 0, 0);
+                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ds[xsym_i(ONE, W, t)], ds[xsym_j(ONE, W, t)], accs[0][t], 0, 0, 0);
             } else if (MODE == 0) {   // level 0: F^T F and (F.F)^T (F.F), both symmetric
                 double f2[4];
 #pragma unroll
                 for (int J = 0; J < 4; ++J) f2[J] = d[J] * d[J];
 #pragma unroll
                 for (int t = 0; t < NS; ++t)
-                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[sym_i(W, t)], d[sym_j(W, t)], accs[0][t], 0, 0, 0);
+                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[xsym_i(ONE, W, t)], d[xsym_j(ONE, W, t)], accs[0][t], 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < NS1; ++t)
                     accs[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[sym_i(W1, t)], f2[sym_j(W1, t)], accs[1][t], 0, 0, 0);
@@ -518,10 +551,10 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
             } else {                  // MODE 1: D^T D;  MODE 2 at level 0: F^T F (d = f)
 #pragma unroll
                 for (int t = 0; t < NS; ++t)
-                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[sym_i(W, t)], d[sym_j(W, t)], accs[0][t], 0, 0, 0);
+                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[xsym_i(ONE, W, t)], d[xsym_j(ONE, W, t)], accs[0][t], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_EVAL);
+        MLMC_COV_EVAL_PRIO(RANKS);
         MLMC_COV_STAMP(2)
         __syncthreads();
         MLMC_COV_STAMP(3)
@@ -561,16 +594,16 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     for (int t = 0; t < ((MODE == 2 && PAIR) ? 0 : NS); ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 16 * sym_i(W, t) + r0 + 4 * r, col = 16 * sym_j(W, t) + c0;
+            const int row = 16 * xsym_i(ONE, W, t) + r0 + 4 * r, col = 16 * xsym_j(ONE, W, t) + c0;
             if (MODE == 0 && PAIR) {
                 prow[2 * NT * NT + row * NT + col] = accs[0][t][r];
-                if (sym_i(W, t) != sym_j(W, t)) prow[2 * NT * NT + col * NT + row] = accs[0][t][r];
+                if (xsym_i(ONE, W, t) != xsym_j(ONE, W, t)) prow[2 * NT * NT + col * NT + row] = accs[0][t][r];
             } else if (MODE == 0) {   // level 0: G0 = F^T F (G1 = G2 below)
                 prow[0 * NT * NT + row * NT + col] = accs[0][t][r];
-                if (sym_i(W, t) != sym_j(W, t)) prow[0 * NT * NT + col * NT + row] = accs[0][t][r];
+                if (xsym_i(ONE, W, t) != xsym_j(ONE, W, t)) prow[0 * NT * NT + col * NT + row] = accs[0][t][r];
             } else {
                 prow[row * NT + col] = accs[0][t][r];
-                if (sym_i(W, t) != sym_j(W, t)) prow[col * NT + row] = accs[0][t][r];
+                if (xsym_i(ONE, W, t) != xsym_j(ONE, W, t)) prow[col * NT + row] = accs[0][t][r];
             }
         }
     if (MODE == 0 && !PAIR) {   // level 0: G1 = G2 = (F.F)^T (F.F), tile list of wave W1
@@ -597,12 +630,12 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 }
 
 template <int KIND, bool PAIR, int MODE, int BD>
-__global__ __launch_bounds__(256, 2) void k_cov_accum_t4(BasisParams bp, 
+__global__ __launch_bounds__(256, COV_T4_WGS) void k_cov_accum_t4(BasisParams bp, 
                                                          const double *__restrict__ fine, const double *__restrict__ coarse,
                                                          const uint8_t *__restrict__ mask, int64_t n, int R,
                                                          double *__restrict__ partials, int64_t *__restrict__ pcounts) {
-    __shared__ double lds_f[64 * ((PAIR ? COV_BATCH : 2 * COV_BATCH) + 2)];       // term-major fine values (level 0: 128 samples)
-    __shared__ double lds_c[PAIR ? 64 * (COV_BATCH + 2) : 1];                      // coarse values
+    __shared__ double lds_f[64 * ((PAIR ? COV_T4_BATCH : 2 * COV_T4_BATCH) + 2)];       // term-major fine values (level 0: 128 samples)
+    __shared__ double lds_c[PAIR ? 64 * (COV_T4_BATCH + 2) : 1];                      // coarse values
     __shared__ int ldc[2][2];
     (void)R;
     // blockIdx.y = component of a vector quantity (see k_cov_accum): one partial row [3 or 1][64][64] per workgroup
@@ -742,7 +775,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     const int NG = gram_mode == 0 ? 3 : 1;
     const int NB = (R + 63) / 64;          // 64 x 64 output blocks per dimension
     const bool pair = d_c != nullptr;
-    const int64_t bsz = T == 4 ? (pair ? COV_BATCH : 2 * COV_BATCH) : cov_batch(T, false, false, pair);
+    const int64_t bsz = T == 4 ? (pair ? COV_T4_BATCH : 2 * COV_T4_BATCH) : cov_batch(T, false, false, pair);
     const int64_t n_batches = (n + bsz - 1) / bsz;
     const size_t width = (size_t)NG * NT * NT;
     const BasisParams &bp = a->basis->p;
@@ -751,7 +784,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
         for (int bj = 0; bj < NB; ++bj) {
             // workgroups per CU: one for the two-window blocks (135 KB of LDS), four for a single 16-term tile (33 KB each:
             // -11..15 % time against two), two otherwise
-            int blocks = rt().n_cu * ((bi != bj) ? 1 : (T == 1 ? 4 : 2));
+            int blocks = rt().n_cu * ((bi != bj) ? 1 : (T == 1 ? 4 : (T == 4 ? COV_T4_WGS : 2)));
             // small chunks: at least four batches per workgroup -- every workgroup leaves NSL partial matrices behind and the
             // reduction reads them all (a 24-component quantity of 10^5 samples spent more time there than in the MFMAs)
             if ((n_batches + 3) / 4 < blocks) blocks = (int)((n_batches + 3) / 4);

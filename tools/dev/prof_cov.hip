@@ -36,7 +36,7 @@ static void run(const char *name, const BasisParams &bp, const double *f, const 
     for (size_t w = 0; w < (size_t)blocks * 4; ++w)
         for (int k = 0; k < 5; ++k) sum[k] += (double)p[w * 6 + k];
     const double nw = (double)blocks * 4;
-    const int64_t bsz = T == 4 ? (PAIR ? COV_BATCH : 2 * COV_BATCH) : cov_batch(T, false, false, PAIR);
+    const int64_t bsz = T == 4 ? (PAIR ? COV_T4_BATCH : 2 * COV_T4_BATCH) : cov_batch(T, false, false, PAIR);
     const double batches_per_wg = (double)((n + bsz - 1) / bsz) / blocks;
     printf("%s: kernel %.3f ms; per wave and batch (cycles): phase1 %.0f  barrier1 %.0f  phase2 %.0f  barrier2 %.0f  total %.0f  (%.1f batches per workgroup)\n",
            name, ms, sum[0] / nw / batches_per_wg, sum[1] / nw / batches_per_wg, sum[2] / nw / batches_per_wg,
@@ -51,6 +51,25 @@ static void run(const char *name, const BasisParams &bp, const double *f, const 
             for (size_t w = 0; w < (size_t)blocks * 4; ++w) { const int id = (int)(p[w * 6 + 5] & 15); sum[id] += (double)(p[w * 6 + 5] >> 24) * 0.01; ++cnt[id]; }
             printf("      wave slot: waves, mean wall us:");
             for (int i = 0; i < 16; ++i) if (cnt[i]) printf("  [%d] %d %.0f", i, cnt[i], sum[i] / cnt[i]);
+            printf("\n");
+        }
+        {   // do the workgroups that share a CU have distinct blockIdx / (grid / workgroups per CU)?  (HW_ID: cu 11:8, sh 12, se 15:13)
+            std::vector<std::vector<int>> on_cu(8 * 256);
+            for (int b2 = 0; b2 < blocks; ++b2) {
+                const unsigned long long h = p[((size_t)b2 * 4) * 6 + 5];
+                const int cu = (int)((h >> 8) & 0xff), xcc = (int)((h >> 16) & 15);
+                on_cu[xcc * 256 + cu].push_back(b2);
+            }
+            int groups = 0, distinct = 0; const int per = blocks / 256 > 0 ? blocks / 256 : 1;
+            for (auto &v : on_cu) {
+                if (v.empty()) continue;
+                ++groups;
+                unsigned seen = 0; bool ok = (int)v.size() == per;
+                for (int b2 : v) { const unsigned bit = 1u << ((b2 / 256) % 8); if (seen & bit) ok = false; seen |= bit; }
+                distinct += ok;
+            }
+            printf("      CUs with workgroups: %d, of them with %d workgroups of distinct blockIdx / 256: %d; first CU:", groups, per, distinct);
+            for (auto &v : on_cu) if (!v.empty()) { for (int b2 : v) printf(" %d", b2); break; }
             printf("\n");
         }
         // per XCD: wall time of its waves (100 MHz ticks) and their clock
@@ -98,10 +117,10 @@ int main(int argc, char **argv) {
     run<2, 0, false>("T=2 level 0, mean+var", bp, f, c, n, 512);
     run<2, 2, false>("T=2 level 0, mean only", bp, f, c, n, 512);
     bp.size = 64;
-    run<4, 0>("T=4 pair, mean+var", bp, f, c, n, 512);
-    run<4, 2>("T=4 pair, mean only", bp, f, c, n, 512);
-    run<4, 0, false>("T=4 level 0, mean+var", bp, f, c, n, 512);
-    run<4, 2, false>("T=4 level 0, mean only", bp, f, c, n, 512);
+    run<4, 0>("T=4 pair, mean+var", bp, f, c, n, 256 * COV_T4_WGS);
+    run<4, 2>("T=4 pair, mean only", bp, f, c, n, 256 * COV_T4_WGS);
+    run<4, 0, false>("T=4 level 0, mean+var", bp, f, c, n, 256 * COV_T4_WGS);
+    run<4, 2, false>("T=4 level 0, mean only", bp, f, c, n, 256 * COV_T4_WGS);
     bp.size = 16;
     run<1, 0>("T=1 pair, mean+var (4 workgroups per CU)", bp, f, c, n, 1024);
     run<1, 2>("T=1 pair, mean only (4 workgroups per CU)", bp, f, c, n, 1024);
