@@ -71,7 +71,7 @@ constexpr int COV_BATCH = 64;
 #endif
 // 64-term kernel: batches of 32 pairs (35 KB of LDS) and FOUR workgroups per CU -- against 64 pairs and two workgroups: -1 %
 // with variances, -8 % mean-only, -3.5 % at level 0 (same-box A/B): four waves per SIMD cover each other's barriers and
-// evaluation phases better than two, at 92 VGPRs the register file allows five.
+// evaluation phases better than two (the kernel fits the 128 registers per lane of that occupancy).
 #ifndef MLMC_COV_T4_BATCH
 #define MLMC_COV_T4_BATCH 32
 #define MLMC_COV_T4_WGS 4
