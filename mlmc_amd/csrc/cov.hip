@@ -80,8 +80,12 @@ constexpr int COV_T4_BATCH = MLMC_COV_T4_BATCH;   // pairs per batch of the 64-t
 constexpr int COV_T4_WGS = MLMC_COV_T4_WGS;       // its workgroups per CU
 // samples per batch: small tiles evaluated from raw samples take 128 sample pairs, or 256 samples at level 0 (one LDS array
 // instead of two, and all four waves evaluate at both kinds of level); everything else 64
+#ifndef MLMC_COV_WIDE_BATCH
+#define MLMC_COV_WIDE_BATCH 32      // pairs per batch of the two-window (off-diagonal) blocks: 70 KB of LDS, two workgroups per
+                                    // CU (64 pairs, 135 KB, one per CU: +3 % with variances, +5 % mean-only at R = 128)
+#endif
 __host__ __device__ constexpr int cov_batch(int T, bool wide, bool vals, bool pair = true) {
-    return (T <= 2 && !wide && !vals) ? (pair ? 128 : 256) : 64;
+    return (T <= 2 && !wide && !vals) ? (pair ? 128 : 256) : ((wide && pair && !vals) ? MLMC_COV_WIDE_BATCH : 64);
 }
 
 // Spline moments in phase 1: at most four B-splines (and phi_0 = 1) are non-zero per value, so instead of selecting the
@@ -109,7 +113,7 @@ __device__ __forceinline__ void cov_spline_store(const TermGen<MLMC_SPLINE> &g, 
 // VALS: `fine` / `coarse` hold already evaluated moment values [n][R] (row-major, NaN rows = masked samples) instead
 // of raw samples: the path for moment functions that are not evaluated in registers (TransformedMoments).
 template <int KIND, int T, bool PAIR, int MODE, int BI = 0, int BJ = 0, bool VALS = false>
-__global__ __launch_bounds__(256, (BI != BJ) ? 1 : 2) void k_cov_accum(BasisParams bp, 
+__global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 64)) ? 1 : 2) void k_cov_accum(BasisParams bp, 
                                                       const double *__restrict__ fine,
                                                       const double *__restrict__ coarse,
                                                       const uint8_t *__restrict__ mask, int64_t n, int R,
@@ -655,7 +659,8 @@ __global__ __launch_bounds__(256, COV_T4_WGS) void k_cov_accum_t4(BasisParams bp
 // line of every partial row), 64 row groups: a three-Gram 16 x 16 tile set already gives 48 workgroups (64 columns per
 // workgroup left a 24-component quantity of small chunks waiting on 12 of them).
 __global__ __launch_bounds__(1024) void k_reduce_cov(const double *__restrict__ partials, int nrows, int NT, int NG, int RP,
-                                                    int roff, int coff, double *__restrict__ totals, int64_t comp_stride) {
+                                                    int roff, int coff, double *__restrict__ totals, int64_t comp_stride,
+                                                    int mirror) {
     __shared__ double lds[64][17];
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int width = NG * NT * NT;
@@ -673,7 +678,11 @@ __global__ __launch_bounds__(1024) void k_reduce_cov(const double *__restrict__ 
         for (int k = 0; k < 64; ++k) v += lds[k][c];
         const int gi = col / (NT * NT), rem = col % (NT * NT);
         const int row = roff + rem / NT, cc = coff + rem % NT;
-        if (row < RP && cc < RP) totals[(int64_t)gi * RP * RP + (int64_t)row * RP + cc] += v;
+        if (row < RP && cc < RP) {
+            totals[(int64_t)gi * RP * RP + (int64_t)row * RP + cc] += v;
+            // level 0: every matrix is symmetric, the block below the diagonal was not computed -- this one transposed stands in
+            if (mirror) totals[(int64_t)gi * RP * RP + (int64_t)cc * RP + row] += v;
+        }
     }
 }
 
@@ -753,7 +762,7 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
     MLMC_HIP_CHECK(hipGetLastError());
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
     hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, 3, a->RP, 0,
-                       0, totals, (int64_t)0);
+                       0, totals, (int64_t)0, 0);
     MLMC_HIP_CHECK(hipGetLastError());
     if (count) {
         hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
@@ -782,9 +791,10 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0);
     for (int bi = 0; bi < NB; ++bi)
         for (int bj = 0; bj < NB; ++bj) {
+            if (!pair && bj < bi) continue;   // level 0: symmetric matrices, block (bj, bi) is mirrored by the reduction
             // workgroups per CU: one for the two-window blocks (135 KB of LDS), four for a single 16-term tile (33 KB each:
             // -11..15 % time against two), two otherwise
-            int blocks = rt().n_cu * ((bi != bj) ? 1 : (T == 1 ? 4 : (T == 4 ? COV_T4_WGS : 2)));
+            int blocks = rt().n_cu * ((bi != bj) ? ((pair && MLMC_COV_WIDE_BATCH < 64) ? 2 : 1) : (T == 1 ? 4 : (T == 4 ? COV_T4_WGS : 2)));
             // small chunks: at least four batches per workgroup -- every workgroup leaves NSL partial matrices behind and the
             // reduction reads them all (a 24-component quantity of 10^5 samples spent more time there than in the MFMAs)
             if ((n_batches + 3) / 4 < blocks) blocks = (int)((n_batches + 3) / 4);
@@ -815,7 +825,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
                 a->alg_bytes += (int64_t)n * (pair ? 16 : 8) * ncomp;
             }
             hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16), ncomp), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, NG,
-                               a->RP, 64 * bi, 64 * bj, totals, a->int_width);
+                               a->RP, 64 * bi, 64 * bj, totals, a->int_width, (!pair && bi != bj) ? 1 : 0);
             MLMC_HIP_CHECK(hipGetLastError());
             if (do_count) {
                 hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
