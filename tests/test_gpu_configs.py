@@ -218,6 +218,8 @@ def test_bench_multi_rank_default_is_config3_sharded(hip):
     assert d["config"]["samples_per_level_total"] == total and d["config"]["samples_per_level_per_gpu"] in (total // 2, total - total // 2)
     assert d["exchange"]["bytes_per_rank"] == 8 * (2 * 5 + 2 * 5 * 64 * 64) and d["exchange"]["allreduce_ms"] > 0
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1.2
+    # the symmetric tiles are computed once: fewer executed flops than the reference's count, a fraction that stays below 1
+    assert 0 < d["roofline"]["executed_mfma"]["frac"] < 1.0 and d["roofline"]["executed_mfma"]["frac"] < d["roofline"]["frac"]
     rc = d["result_check"]
     assert rc["mean0"] == 1.0 and rc["var0"] == 0.0 and len(rc["n_estimated"]) == 5
     assert all(0 < r < 0.01 * total for r in rc["n_removed"])                          # both shards were counted
