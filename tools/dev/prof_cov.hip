@@ -53,6 +53,17 @@ static void run(const char *name, const BasisParams &bp, const double *f, const 
             for (int i = 0; i < 16; ++i) if (cnt[i]) printf("  [%d] %d %.0f", i, cnt[i], sum[i] / cnt[i]);
             printf("\n");
         }
+        {   // by rank on the CU (blockIdx / 256 for a full grid): mean and max wall time of the workgroups
+            const int per = blocks / 256 > 0 ? blocks / 256 : 1;
+            printf("      rank on the CU: mean / max wall us:");
+            for (int r = 0; r < per; ++r) {
+                double sum = 0, mx = 0; int cnt = 0;
+                for (int b2 = r * 256; b2 < (r + 1) * 256 && b2 < blocks; ++b2)
+                    for (int w = 0; w < 4; ++w) { const double us = (double)(p[((size_t)b2 * 4 + w) * 6 + 5] >> 24) * 0.01; sum += us; mx = std::max(mx, us); ++cnt; }
+                if (cnt) printf("  [%d] %.0f / %.0f", r, sum / cnt, mx);
+            }
+            printf("\n");
+        }
         {   // do the workgroups that share a CU have distinct blockIdx / (grid / workgroups per CU)?  (HW_ID: cu 11:8, sh 12, se 15:13)
             std::vector<std::vector<int>> on_cu(8 * 256);
             for (int b2 = 0; b2 < blocks; ++b2) {
