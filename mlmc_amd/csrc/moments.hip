@@ -410,6 +410,9 @@ constexpr int SPLIT_HEAD = MLMC_SPLIT_HEAD;      // of 64 terms (48 < R <= 64)
 // kernel on BASELINE configs[1], same-box A/B.)
 __host__ __device__ constexpr int split_max(int ht, int tt) { return ht > tt ? ht : tt; }
 // the two workgroups of a CU take turns at the higher issue priority, like the waves of k_moments_accum (see accum_samples)
+#ifndef MLMC_SPLIT_WPS
+#define MLMC_SPLIT_WPS 2      // workgroups per CU (= waves per SIMD) the split kernel's registers are held to (3: +4 % time)
+#endif
 #ifdef MLMC_SPLIT_NO_PRIO
 #define MLMC_SPLIT_PRIO_INIT
 #define MLMC_SPLIT_PRIO_TRIP
@@ -418,10 +421,10 @@ __host__ __device__ constexpr int split_max(int ht, int tt) { return ht > tt ? h
 #define MLMC_SPLIT_PRIO_BITS 16
 #endif
 #define MLMC_SPLIT_PRIO_INIT                                                                                              \
-    const unsigned prio_phase = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u) & 1u; /* HW_ID.wave_id */     \
+    const unsigned prio_phase = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u) % MLMC_SPLIT_WPS; /* HW_ID.wave_id */ \
     unsigned long long prio_clock = __builtin_amdgcn_s_memtime();
 #define MLMC_SPLIT_PRIO_TRIP                                                                                              \
-    if ((((unsigned)(prio_clock >> MLMC_SPLIT_PRIO_BITS)) & 1u) == prio_phase) __builtin_amdgcn_s_setprio(2);             \
+    if ((((unsigned)(prio_clock >> MLMC_SPLIT_PRIO_BITS)) % MLMC_SPLIT_WPS) == prio_phase) __builtin_amdgcn_s_setprio(2); \
     else __builtin_amdgcn_s_setprio(0);                                                                                   \
     prio_clock = __builtin_amdgcn_s_memtime();
 #endif
@@ -836,7 +839,7 @@ static int split_go(int op, const BasisParams &bp, const SegTable *tab, int tota
 }
 static int split_dispatch(int op, bool plain, const BasisParams &bp, const SegTable *tab, int total_blocks, double *partials,
                           int64_t *pcounts, int *out) {
-#define MLMC_SPLIT_GO(KIND, P) split_go<KIND, P, SPLIT_HEAD, 64 - SPLIT_HEAD, 2>(op, bp, tab, total_blocks, partials, pcounts, out)
+#define MLMC_SPLIT_GO(KIND, P) split_go<KIND, P, SPLIT_HEAD, 64 - SPLIT_HEAD, MLMC_SPLIT_WPS>(op, bp, tab, total_blocks, partials, pcounts, out)
     if (bp.kind == MLMC_LEGENDRE) return plain ? MLMC_SPLIT_GO(MLMC_LEGENDRE, true) : MLMC_SPLIT_GO(MLMC_LEGENDRE, false);
     return plain ? MLMC_SPLIT_GO(MLMC_MONOMIAL, true) : MLMC_SPLIT_GO(MLMC_MONOMIAL, false);
 #undef MLMC_SPLIT_GO
