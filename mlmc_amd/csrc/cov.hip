@@ -526,7 +526,12 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         // -- was 11 % slower at a pair level: a single wave per SIMD leaves every stall of the matrix stream exposed.  The same
         // pipeline with batches of 32 pairs, two 35 KB images per workgroup, two workgroups per CU and one evaluator wave
         // (9 / 11 / 11 / 11 MFMAs per k-step): +10 % with variances, +17 % mean-only -- the evaluator wave's in-order stream
-        // of dependent recurrence steps between its matrix instructions paces the whole workgroup.)
+        // of dependent recurrence steps between its matrix instructions paces the whole workgroup.  All levels of an estimate in
+        // ONE launch -- every workgroup walks the levels one after the other, pair and level-0 bodies in one kernel, to pay
+        // the ramp and the uneven end of a launch once instead of five times: +1.7 % (the combined kernel does not fit the 128
+        // registers per lane of four workgroups per CU: 210 spilled VGPRs), and compiled in the same translation unit it
+        // changed the register allocation of the stand-alone kernel, too.  A static schedule that gives the youngest
+        // workgroup of a CU 15 batches where the others get 16: no change.)
 #pragma unroll
         for (int ks = 0; ks < BATCH / 4; ++ks) {
             const int col = 4 * ks + (lane >> 4);
