@@ -669,7 +669,10 @@ __global__ __launch_bounds__(256, COV_T4_WGS) void k_cov_accum_t4(BasisParams bp
     if (PAIR) coarse += (int64_t)blockIdx.y * n;
     partials += (int64_t)blockIdx.y * gridDim.x * (((MODE == 0) ? 3 : 1) * 64 * 64);
     if (blockIdx.y) pcounts = nullptr;
-    switch (threadIdx.x >> 6) {   // every wave runs its own specialisation (same barrier count in all of them)
+    // every wave runs its own specialisation (same barrier count in all of them); readfirstlane makes the wave index a scalar,
+    // so this is a scalar branch -- as a per-lane switch the compiler predicates the four bodies with exec masks, and a
+    // wave must never walk through another body's s_barrier with an empty mask
+    switch (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) {
         case 0: cov_t4_body<KIND, PAIR, MODE, BD, 0>(bp, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
         case 1: cov_t4_body<KIND, PAIR, MODE, BD, 1>(bp, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
         case 2: cov_t4_body<KIND, PAIR, MODE, BD, 2>(bp, fine, coarse, mask, n, partials, pcounts, lds_f, lds_c, ldc); break;
