@@ -189,6 +189,9 @@ def roofline_block(mode, basis, R, pairs_per_step, singles_per_step, kt, steps, 
         ex = 512 * ((2 * t * t + t * (t + 1) // 2) * pairs_per_step + t * (t + 1) * singles_per_step)
         ex_tf = ex / step_kernel_s / 1e12 if step_kernel_s > 0 else 0.0
         out["executed_mfma"] = {"flops_per_step": int(ex), "achieved": round(ex_tf, 3), "frac": round(ex_tf / peak, 4)}
+        out["note"] = ("achieved / frac count the reference's flops (SURVEY 8(d): 6 R^2 + 14 R per pair); the kernel computes the "
+                       "symmetric Gram tiles once and executes fewer, so frac can pass 1 -- executed_mfma is the matrix pipe's "
+                       "real load")
     return out
 
 
