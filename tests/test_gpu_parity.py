@@ -544,6 +544,11 @@ def test_covariance_full_size_properties(hip):
     rms = np.sqrt(spm / n[:, None]) * n[:, None]
     assert close(S[:, 0, :], sm, rms, 1e-10) and close(SP[:, 0, :], spm, None, 1e-10)
     assert np.all(SP >= 0)
+    # run to run: bitwise (static batch schedule, fixed-order reduction; the issue priorities of the kernel change timing only)
+    for l in range(L):
+        acc.push(l, *dev[l]) if l else (acc.reset(), acc.push(l, *dev[l]))
+    again = acc.finalize()
+    assert np.array_equal(again[0], n) and np.array_equal(again[2], s) and np.array_equal(again[3], sp)
     # Cauchy-Schwarz on the level-0 second moments: (sum f_i f_j)^2 <= (sum f_i^2)(sum f_j^2)
     d0 = np.diag(S[0])
     assert np.all(S[0] ** 2 <= np.outer(d0, d0) * (1 + 1e-12))
