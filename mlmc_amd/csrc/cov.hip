@@ -530,7 +530,8 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         // ONE launch -- every workgroup walks the levels one after the other, pair and level-0 bodies in one kernel, to pay
         // the ramp and the uneven end of a launch once instead of five times: +1.7 % (the combined kernel does not fit the 128
         // registers per lane of four workgroups per CU: 210 spilled VGPRs), and compiled in the same translation unit it
-        // changed the register allocation of the stand-alone kernel, too.  A static schedule that gives the youngest
+        // changed the register allocation of the stand-alone kernel, too; the four pair levels alone in one launch, from a
+        // translation unit of its own: -0.3 % -- the end of a launch is not where the time goes.  A static schedule that gives the youngest
         // workgroup of a CU 15 batches where the others get 16: no change.)
 #pragma unroll
         for (int ks = 0; ks < BATCH / 4; ++ks) {
