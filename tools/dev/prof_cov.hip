@@ -1,8 +1,10 @@
-// Diagnostic (not part of the library): per-wave shader cycles of the phases of k_cov_accum<LEGENDRE, T = 2, pair> (R <= 32):
-// phase 1 (evaluation), wait at the barrier behind it, phase 2 (MFMA), wait at the barrier behind it.
+// Diagnostic (not part of the library): per-wave shader cycles of the phases of the covariance kernels (R <= 16, <= 32, 64; pair
+// levels and level 0; with variances and mean-only): phase 1 (evaluation), wait at the barrier behind it, phase 2 (MFMA), wait at
+// the barrier behind it -- averaged, per wave index, with the SIMD each wave ran on; wall time of the workgroups by wave slot,
+// by rank on the CU (blockIdx / 256) and by XCD with its clock.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DMLMC_PROF_COV -I include -I mlmc_amd/csrc
 //        tools/dev/prof_cov.hip mlmc_amd/csrc/api.hip mlmc_amd/csrc/moments.hip mlmc_amd/csrc/maxent.hip mlmc_amd/csrc/select.hip
-//        mlmc_amd/csrc/expr.hip mlmc_amd/csrc/expr_jit.hip mlmc_amd/csrc/synth.hip -o tools/dev/prof_cov
+//        mlmc_amd/csrc/expr.hip mlmc_amd/csrc/expr_jit.hip mlmc_amd/csrc/synth.hip -ldl -o tools/dev/prof_cov
 #include "../../mlmc_amd/csrc/cov.hip"
 #include <algorithm>
 #include <cstdio>
