@@ -28,6 +28,10 @@ import time
 
 import numpy as np
 
+# the hosts of this pool support dmabuf IPC only: RCCL between the ranks of one node needs this before HIP starts (it is
+# exported by the image; kept here for launchers that build their own environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
