@@ -74,7 +74,8 @@ class LevelAccumulator:
         self._keepalive = []
 
     def close(self):
-        if getattr(self, "_h", None) is not None and _lib._lib is not None:
+        # at interpreter shutdown the module globals may already be gone (`_lib` is None then): nothing left to free
+        if getattr(self, "_h", None) is not None and _lib is not None and _lib._lib is not None:
             _lib._lib.mlmc_accum_destroy(self._h)
             self._h = None
 
