@@ -83,6 +83,9 @@ __device__ unsigned long long *g_prof_cov;
         else __builtin_amdgcn_s_setprio(MLMC_COV_PRIO_EVAL);                                          \
     } while (0)
 constexpr int COV_BATCH = 64;
+#ifndef MLMC_COV_BLK22
+#define MLMC_COV_BLK22 1
+#endif
 #ifndef MLMC_COV_T4_ONE_LIST
 #define MLMC_COV_T4_ONE_LIST 1
 #endif
@@ -416,9 +419,17 @@ __host__ __device__ constexpr int sym_j(int w, int t) { return t == 0 ? w : (w <
 __host__ __device__ constexpr int psym_n(int w) { return w == 0 ? 1 : 3; }
 __host__ __device__ constexpr int psym_i(int w, int t) { return t == 0 ? w : (w == 1 ? (t == 1 ? 1 : 0) : (w == 2 ? (t == 1 ? 2 : 0) : (t == 1 ? 0 : 1))); }
 __host__ __device__ constexpr int psym_j(int w, int t) { return t == 0 ? w : (w == 1 ? (t == 1 ? 2 : 1) : (w == 2 ? (t == 1 ? 3 : 2) : 3)); }
-__host__ __device__ constexpr int xsym_n(bool one, int w) { return one ? psym_n(w) : sym_n(w); }
-__host__ __device__ constexpr int xsym_i(bool one, int w, int t) { return one ? psym_i(w, t) : sym_i(w, t); }
-__host__ __device__ constexpr int xsym_j(bool one, int w, int t) { return one ? psym_j(w, t) : sym_j(w, t); }
+// 2 x 2 tile blocks (pair levels with variances): wave w = 2 a + b owns rows {2a, 2a+1} x columns {2b, 2b+1} of G0 and G1, and of
+// the symmetric G2  w0: (0,0) (0,1) (1,1)   w1: (0,2) (0,3)   w2: (1,2) (1,3)   w3: (2,2) (2,3) (3,3) -- the diagonal waves then
+// need the fine / coarse fragments of two row blocks only (4 LDS reads and 10 vector instructions per k-step instead of 8 and
+// 15), the others 8 and 14; 11 / 10 / 10 / 11 MFMAs, wave 1 evaluates.
+__host__ __device__ constexpr int bsym_n(int w) { return (w == 0 || w == 3) ? 3 : 2; }
+__host__ __device__ constexpr int bsym_i(int w, int t) { return w == 0 ? (t == 2 ? 1 : 0) : (w == 1 ? 0 : (w == 2 ? 1 : (t == 2 ? 3 : 2))); }
+__host__ __device__ constexpr int bsym_j(int w, int t) { return w == 0 ? (t == 0 ? 0 : 1) : (w == 1 ? 2 + t : (w == 2 ? 2 + t : (t == 0 ? 2 : 3))); }
+// kind of list: 0 = two evaluators (2/2/3/3), 1 = one evaluator (1/3/3/3), 2 = 2 x 2 blocks (3/2/2/3)
+__host__ __device__ constexpr int xsym_n(int kind, int w) { return kind == 2 ? bsym_n(w) : (kind == 1 ? psym_n(w) : sym_n(w)); }
+__host__ __device__ constexpr int xsym_i(int kind, int w, int t) { return kind == 2 ? bsym_i(w, t) : (kind == 1 ? psym_i(w, t) : sym_i(w, t)); }
+__host__ __device__ constexpr int xsym_j(int kind, int w, int t) { return kind == 2 ? bsym_j(w, t) : (kind == 1 ? psym_j(w, t) : sym_j(w, t)); }
 
 template <int KIND, bool PAIR, int MODE, int BD, int W>
 __device__ __forceinline__ void cov_t4_body(const BasisParams &bp, 
@@ -429,7 +440,9 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     constexpr int NT = 64;
     constexpr int TA = 64 * BD;
     constexpr int N_EVAL = TA + NT;
-    constexpr bool ONE = PAIR && MLMC_COV_T4_ONE_LIST && COV_T4_BATCH == 32;   // tile lists for a single evaluator wave
+    constexpr bool BLK = PAIR && MODE == 0 && MLMC_COV_BLK22 && COV_T4_BATCH == 32;   // 2 x 2 tile blocks per wave
+    constexpr bool BLK2 = PAIR && MODE == 2 && MLMC_COV_BLK22 && COV_T4_BATCH == 32;  // the same for the mean-only G0
+    constexpr int ONE = BLK ? 2 : ((PAIR && MLMC_COV_T4_ONE_LIST && COV_T4_BATCH == 32) ? 1 : 0);   // kind of tile list
     constexpr int NS = xsym_n(ONE, W);
     // level 0 with variances has TWO symmetric matrices: the second one takes the tile list of wave W + 2, so every wave
     // issues 2 + 3 = 5 MFMAs per k-step (the same list for both gave 6 / 6 / 4 / 4 and two waves waited at the barrier:
@@ -459,8 +472,9 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     // The evaluators are the first waves: they own fewer tiles of a symmetric matrix than the others.  (Waves 2-3 as
     // evaluators of 64-pair batches: +5 % on a mean-only pair level, same-box A/B.  Which SIMD a wave runs on rotates from workgroup to
     // workgroup -- HW_ID histogram in tools/dev/prof_cov.hip -- so no assignment balances the SIMDs of a CU exactly.)
-    constexpr bool evaluator = W < COV_T4_BATCH / 32;
-    const int samp = PAIR ? (W * 32 + (lane & 31)) : (W * 64 + lane);
+    constexpr bool evaluator = BLK ? (W == 1) : (W < COV_T4_BATCH / 32);
+    constexpr int EW = BLK ? 0 : W;              // index of this wave among the evaluators
+    const int samp = PAIR ? (EW * 32 + (lane & 31)) : (EW * 64 + lane);
     const bool is_coarse = PAIR && (lane >> 5);
     const double *__restrict__ src = is_coarse ? coarse : fine;
     // (Measured and not adopted: writing d = f - c and s = f + c instead of f and c -- one half-wave exchange and one add per
@@ -549,7 +563,24 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
                     sm[J] = f + c;
                 }
             }
-            if (MODE == 0 && PAIR) {
+            if (BLK) {
+                constexpr int RA = 2 * (W >> 1), CA = 2 * (W & 1);      // first row block, first column block
+                double ds[4];
+#pragma unroll
+                for (int J = 0; J < 4; ++J) ds[J] = d[J] * sm[J];       // only the ones the tile list names survive
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const double dr2 = d[RA + r] * d[RA + r];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        accf[0][2 * r + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[RA + r], sm[CA + c], accf[0][2 * r + c], 0, 0, 0);
+                        accf[1][2 * r + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(dr2, sm[CA + c] * sm[CA + c], accf[1][2 * r + c], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NS; ++t)
+                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ds[xsym_i(ONE, W, t)], ds[xsym_j(ONE, W, t)], accs[0][t], 0, 0, 0);
+            } else if (MODE == 0 && PAIR) {
                 const double dw2 = d[W] * d[W];
                 double ds[4];
 #pragma unroll
@@ -571,6 +602,13 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #pragma unroll
                 for (int t = 0; t < NS1; ++t)
                     accs[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[sym_i(W1, t)], f2[sym_j(W1, t)], accs[1][t], 0, 0, 0);
+            } else if (MODE == 2 && PAIR && BLK2) {   // covariance mean only: G0 = D^T S, a 2 x 2 block of tiles per wave
+                constexpr int RA = 2 * (W >> 1), CA = 2 * (W & 1);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        accf[0][2 * r + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[RA + r], sm[CA + c], accf[0][2 * r + c], 0, 0, 0);
             } else if (MODE == 2 && PAIR) {   // covariance mean only: G0 = D^T S, row tile W
 #pragma unroll
                 for (int J = 0; J < 4; ++J)
@@ -606,7 +644,9 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         for (int J = 0; J < 4; ++J)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * W + r0 + 4 * r, col = 16 * J + c0;
+                // row-of-tiles mapping: tile (W, J); 2 x 2 blocks: accumulator J = 2 r' + c' is tile (2 (W >> 1) + r', 2 (W & 1) + c')
+                const int tr = BLK ? 2 * (W >> 1) + (J >> 1) : W, tc = BLK ? 2 * (W & 1) + (J & 1) : J;
+                const int row = 16 * tr + r0 + 4 * r, col = 16 * tc + c0;
                 prow[0 * NT * NT + row * NT + col] = accf[0][J][r];
                 prow[1 * NT * NT + row * NT + col] = accf[1][J][r];
             }
@@ -615,7 +655,10 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #pragma unroll
         for (int J = 0; J < 4; ++J)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) prow[(16 * W + r0 + 4 * r) * NT + 16 * J + c0] = accf[0][J][r];
+            for (int r = 0; r < 4; ++r) {
+                const int tr = BLK2 ? 2 * (W >> 1) + (J >> 1) : W, tc = BLK2 ? 2 * (W & 1) + (J & 1) : J;
+                prow[(16 * tr + r0 + 4 * r) * NT + 16 * tc + c0] = accf[0][J][r];
+            }
     }
 #pragma unroll
     for (int t = 0; t < ((MODE == 2 && PAIR) ? 0 : NS); ++t)
