@@ -65,17 +65,60 @@ CONFIGS = {
 }
 
 
-def synth_device(level, n, steps, seed, device):
-    """x ~ N(0,1); fine = x + h_l sqrt(1e-4+|x|); coarse = x + h_{l-1} sqrt(1e-4+|x|)
-    (formula of mlmc/sim/synth_simulation.py:37-46), generated in HBM."""
+SYNTH_BLOCK = 1_000_000
+
+
+def synth_level_host_blocks(level, lo, hi, steps, seed=1234):
+    """samples [lo, hi) of level `level` of the synthetic workload, generated on the HOST with NumPy's
+    default_rng(seed + level) in blocks of 1e6 samples -- x ~ N(0,1); fine = x + h_l sqrt(1e-4+|x|); coarse = x + h_{l-1}
+    sqrt(1e-4+|x|) (formula of mlmc/sim/synth_simulation.py:37-46) -- so that the GPU and the CPU baseline consume identical
+    bits.  The stream of a level is ONE generator: a shard [lo, hi) draws (and drops) the blocks in front of it, so the
+    shards of N ranks are exactly the slices of the one-GPU job.  Yields (offset - lo, fine, coarse | None)."""
+    rng = np.random.default_rng(seed + level)
+    pos = 0
+    while pos < hi:
+        m = min(SYNTH_BLOCK, hi - pos)
+        x = rng.standard_normal(m)
+        if pos + m > lo:
+            a, b = max(lo - pos, 0), m
+            x = x[a:b]
+            root = np.sqrt(1e-4 + np.abs(x))
+            yield pos + a - lo, x + steps[level] * root, (None if level == 0 else x + steps[level - 1] * root)
+        pos += m
+
+
+def synth_device(levels, lo, hi, steps, device, seed=1234):
+    """The host-generated workload of `levels` (list of level indices), samples [lo, hi) of each, uploaded to HBM:
+    [(fine, coarse | None)] of torch tensors.  One generator thread per level (NumPy's generators and ufuncs release the GIL)."""
+    import threading
     import torch
-    g = torch.Generator(device=device)
-    g.manual_seed(seed + level)
-    x = torch.randn(n, dtype=torch.float64, device=device, generator=g)
-    root = torch.sqrt(1e-4 + torch.abs(x))
-    fine = (x + steps[level] * root).contiguous()
-    coarse = None if level == 0 else (x + steps[level - 1] * root).contiguous()
-    return fine, coarse
+    n = hi - lo
+    out = {}
+    for l in levels:
+        out[l] = (torch.empty(n, dtype=torch.float64, device=device),
+                  None if l == 0 else torch.empty(n, dtype=torch.float64, device=device))
+    errors = []
+
+    def work(l):
+        try:
+            torch.cuda.set_device(device)
+            fine, coarse = out[l]
+            for off, f, c in synth_level_host_blocks(l, lo, hi, steps, seed):
+                fine[off:off + f.size].copy_(torch.from_numpy(f))
+                if c is not None:
+                    coarse[off:off + c.size].copy_(torch.from_numpy(c))
+        except Exception as e:      # surfaced by the caller
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(l,)) for l in levels]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    torch.cuda.synchronize()
+    return [out[l] for l in levels]
 
 
 class Ctx:
@@ -133,6 +176,7 @@ def timed_loop(step, acc, steps, warmup, preroll_ms, ctx):
         for _ in range(warmup):
             step()
         acc.kernel_time()                               # drop the warm-up launches from the totals
+        acc.kernel_flops()
         ctx.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -144,13 +188,14 @@ def timed_loop(step, acc, steps, warmup, preroll_ms, ctx):
     # HIP events around every launch of the dominant kernel in the timed region, recorded on the library's stream and
     # read back once, after the clock has stopped
     kt = list(acc.kernel_time())
+    mfma_flops = acc.kernel_flops()
     elapsed, k_ms = ctx.max_over_ranks([elapsed, kt[0]])
-    return elapsed, pre, res, [k_ms, int(kt[1]), int(kt[2])]
+    return elapsed, pre, res, [k_ms, int(kt[1]), int(kt[2]), int(mfma_flops)]
 
 
 def alg_flops(mode, R, pairs, singles):
-    """Algorithmic flops by the reference's operation count (SURVEY 8(d)): 14 R per pair, 8 R per level-0 sample;
-    the covariance adds 6 R^2 (three R x R x n contractions) per pair, 4 R^2 at level 0."""
+    """Flops by the reference's operation count: 14 R per pair, 8 R per level-0 sample; the covariance adds
+    6 R^2 (three R x R x n contractions, every entry of every matrix) per pair, 4 R^2 at level 0."""
     if mode == "moments":
         return (14 * R) * pairs + (8 * R) * singles
     return (14 * R + 6 * R * R) * pairs + (8 * R + 4 * R * R) * singles
@@ -159,8 +204,13 @@ def alg_flops(mode, R, pairs, singles):
 def roofline_block(mode, basis, R, pairs_per_step, singles_per_step, kt, steps, config_key):
     """Roofline of the dominant kernel of one block.  The BINDING roof is the top-level one: fp64 VALU for the moments
     kernel at R >= 12 (28 flop/B at R = 32 against a ridge of 9.8), fp64 MFMA for the covariance kernel; the HBM figures
-    (algorithmic bytes / average launch duration) ride beside it under "hbm"."""
-    k_ms, launches, k_bytes = kt
+    (algorithmic bytes / average launch duration) ride beside it under "hbm".
+    Covariance: `achieved` / `frac` count the flops the matrix pipe EXECUTES -- 512 per 16 x 16 tile and sample, the tiles
+    of the symmetric Gram matrices once (SURVEY 8(d) allows symmetric halves; R = 64: 42 tiles per pair, 20 per level-0
+    sample), as reported by the library (mlmc_accum_kernel_flops) -- a physical fraction of the fp64 matrix peak.  The
+    reference-form count (6 R^2 + 14 R per pair: every entry of three R x R matrices) rides beside it under
+    "reference_form"; it exceeds what any kernel that uses the symmetry has to execute, so its fraction can pass 1."""
+    k_ms, launches, k_bytes, mfma_flops = kt
     per_step = max(launches // max(steps, 1), 1)
     avg_launch_ms = k_ms / max(launches, 1)
     gbs = (k_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
@@ -169,34 +219,26 @@ def roofline_block(mode, basis, R, pairs_per_step, singles_per_step, kt, steps, 
               "launches_per_step": per_step}
     if basis == "Spline":
         kname = "k_spline_accum"
-        traffic, src = pmc_traffic(config_key, kname, per_step)
-        return dict(bound="hbm", **hbm, traffic=traffic, traffic_source=src, kernel=kname, **common,
+        return dict(bound="hbm", **hbm, **pmc_traffic(config_key, kname), kernel=kname, **common,
                     note="sparse accumulation (<= 8 of the R sums touched per sample pair): no dense flop count applies")
     flops = alg_flops(mode, R, pairs_per_step, singles_per_step)
     step_kernel_s = (k_ms / 1e3) / max(steps, 1)
     tflops = flops / step_kernel_s / 1e12 if step_kernel_s > 0 else 0.0
     if mode == "moments":
-        kname, bound, peak = "k_moments_accum", "valu_f64", FP64_VALU_PEAK_TFLOPS
+        kname, peak = "k_moments_accum", FP64_VALU_PEAK_TFLOPS
         if R < 12:                                      # HBM-bound below the ridge
-            traffic, src = pmc_traffic(config_key, kname, per_step)
-            return dict(bound="hbm", **hbm, traffic=traffic, traffic_source=src, kernel=kname, **common)
-    else:
-        kname, bound, peak = "k_cov_accum", "mfma", FP64_MFMA_PEAK_TFLOPS
-    traffic, src = pmc_traffic(config_key, kname, per_step)
-    out = dict(bound=bound, achieved=round(tflops, 3), peak=peak, unit="TFLOP/s", frac=round(tflops / peak, 4),
-               traffic=traffic, traffic_source=src, kernel=kname, alg_flops_per_step=int(flops), hbm=hbm, **common)
-    if mode != "moments" and R <= 64:
-        # what the kernel EXECUTES on the matrix pipe: 16 x 16 tiles, G0 and G1 in full, the symmetric G2 (level 0: both
-        # matrices) in its upper tiles only -- fewer flops than the reference's count above, so "frac" can approach 1 while
-        # the pipe is ~0.8 busy with matrix instructions; the rest is the kernel's own fp64 vector work on the same pipe
-        t = (R + 15) // 16
-        ex = 512 * ((2 * t * t + t * (t + 1) // 2) * pairs_per_step + t * (t + 1) * singles_per_step)
-        ex_tf = ex / step_kernel_s / 1e12 if step_kernel_s > 0 else 0.0
-        out["executed_mfma"] = {"flops_per_step": int(ex), "achieved": round(ex_tf, 3), "frac": round(ex_tf / peak, 4)}
-        out["note"] = ("achieved / frac count the reference's flops (SURVEY 8(d): 6 R^2 + 14 R per pair); the kernel computes the "
-                       "symmetric Gram tiles once and executes fewer, so frac can pass 1 -- executed_mfma is the matrix pipe's "
-                       "real load")
-    return out
+            return dict(bound="hbm", **hbm, **pmc_traffic(config_key, kname), kernel=kname, **common)
+        return dict(bound="valu_f64", achieved=round(tflops, 3), peak=peak, unit="TFLOP/s", frac=round(tflops / peak, 4),
+                    **pmc_traffic(config_key, kname), kernel=kname, alg_flops_per_step=int(flops), hbm=hbm, **common)
+    kname, peak = "k_cov_accum", FP64_MFMA_PEAK_TFLOPS
+    ex = mfma_flops / max(steps, 1)
+    ex_tf = ex / step_kernel_s / 1e12 if step_kernel_s > 0 else 0.0
+    return dict(bound="mfma", achieved=round(ex_tf, 3), peak=peak, unit="TFLOP/s", frac=round(ex_tf / peak, 4),
+                **pmc_traffic(config_key, kname), kernel=kname, executed_mfma_flops_per_step=int(ex),
+                reference_form={"alg_flops_reference_form": int(flops), "achieved": round(tflops, 3), "frac": round(tflops / peak, 4),
+                                "note": "6 R^2 + 14 R per pair (4 R^2 + 8 R at level 0), quantity_estimate.py:131-147: every entry of "
+                                        "every Gram matrix; the kernel computes symmetric tiles once and executes fewer"},
+                hbm=hbm, **common)
 
 
 def host_formulas(n, s, sp, level_stats):
@@ -329,8 +371,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5, 6],
-                    help="default: 3 (BASELINE configs[2]) + secondary blocks at N = 1, configs[3] sharded at N > 1")
+    ap.add_argument("--config", type=lambda v: int(v) if v.isdigit() else v, default=None, choices=[2, 3, 4, 5, 6, "sharded"],
+                    help="default: 3 (BASELINE configs[2]) + secondary blocks at N = 1, configs[3] sharded at N > 1; "
+                         "`--gpus 1 --config sharded` runs the WHOLE configs[3] job (5 x 1e8 samples, 8 GB) on one GPU: the "
+                         "N = 1 point of the same strong-scaling workload the N > 1 default measures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1 default line without the secondary blocks")
     ap.add_argument("--preroll-ms", type=float, default=250.0,
@@ -398,11 +442,15 @@ def main():
         lo, hi = shard_bounds(total, rank, world)
         cfg["n_per_level"] = hi - lo
         cfg["n_total_per_level"] = total
+    else:
+        lo, hi = 0, cfg["n_per_level"]
     n_l = cfg["n_per_level"]
     steps_h = [s[0] for s in determine_level_parameters(L, [0.5, 0.01])] if L > 1 else [0.01]
     fn = Spline(R, DOMAIN) if cfg.get("basis") == "Spline" else Legendre(R, DOMAIN)
-    data = [synth_device(l, n_l, steps_h, 1234 + 1000 * rank, dev) for l in range(L)]
-    torch.cuda.synchronize()
+    # host-generated default_rng(1234 + l) samples; sharded: this rank's slice of the one stream per level,
+    # otherwise (weak scaling, fixed work per GPU) every rank its own stream
+    data_seed = 1234 if key == "sharded" else 1234 + 1000 * rank
+    data = synth_device(list(range(L)), lo, hi, steps_h, dev, seed=data_seed)
 
     head = estimate_block(cfg, data, fn, steps_h, ctx, args.steps, args.warmup, args.preroll_ms, key)
     out = {
@@ -442,8 +490,7 @@ def main():
             c2 = CONFIGS[k2]
             sh = [s[0] for s in determine_level_parameters(c2["L"], [0.5, 0.01])]
             f2 = Legendre(c2["R"], DOMAIN)
-            d2 = [synth_device(l, c2["n_per_level"], sh, 1234, dev) for l in range(c2["L"])]
-            torch.cuda.synchronize()
+            d2 = synth_device(list(range(c2["L"])), 0, c2["n_per_level"], sh, dev)
             blk = estimate_block(c2, d2, f2, sh, ctx, st, wu, 100.0, 3 if k2 == "north_star" else k2)
             blk["config"] = {"workload": c2["workload"], "levels": c2["L"], "samples_per_level_per_gpu": c2["n_per_level"],
                              "n_moments": c2["R"], "estimate": c2["mode"]}
@@ -495,7 +542,7 @@ def tree_bench(args, cfg, world, rank, dev, dist):
     for l in range(L):
         rows = []
         for r in range(2):
-            f, c = synth_device(l, n_l, steps, 1234 + 1000 * rank + 77 * r, dev)
+            f, c = synth_device([l], 0, n_l, steps, dev, seed=1234 + 1000 * rank + 77 * r)[0]
             rows.append(f.reshape(-1, 1).contiguous() if c is None else torch.stack([f, c], dim=1).contiguous())
         stored.append(rows)
     torch.cuda.synchronize()
@@ -530,7 +577,7 @@ def tree_bench(args, cfg, world, rank, dev, dist):
     x_ms, x_launches, x_bytes = plan.kernel_time()
     a_ms, a_launches, _ = acc.kernel_time()
     gbs = (x_bytes / 1e9) / (x_ms / 1e3) if x_ms > 0 else 0.0
-    traffic, traffic_src = pmc_avg_bytes_per_dispatch(6, "k_expr")
+    traffic = pmc_traffic(6, "k_expr")
     out = {
         "metric": "moment-evals/sec (samples x n_moments)", "value": world * L * n_l * R * steps_k / elapsed,
         "unit": "moment-evals/s", "n_gpus": world, "steps": steps_k, "warmup": warm, "preroll_steps": preroll_steps,
@@ -540,7 +587,7 @@ def tree_bench(args, cfg, world, rank, dev, dist):
                    "tree": "(x - 0.1) * (x - 0.1) / (np.abs(y) + 1.0)", "program_instructions": len(plan.prog),
                    "program_registers": plan.n_regs, "stored_rows_read": len(plan.in_rows), "result_rows": plan.n_out},
         "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_expr",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), **traffic, "kernel": "k_expr",
                      "avg_launch_ms": round(x_ms / max(x_launches, 1), 5),
                      "alg_bytes_per_launch": int(x_bytes / max(x_launches, 1)), "launches_per_step": x_launches // max(steps_k, 1),
                      "moments_kernel_ms_per_step": round(a_ms / max(steps_k, 1), 5)},
@@ -615,6 +662,19 @@ def pdf_solve_timing(fn, L, data, LevelAccumulator, level_stats):
             "nit": int(res.nit), "grad_norm": float(res.fun_norm), "success": bool(res.success)}
 
 
+def csrc_sha():
+    """sha256 over the kernel sources (mlmc_amd/csrc/*.hip, *.hpp, include/mlmc_hip.h): names the build a profile belongs to."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "mlmc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mlmc_amd", "csrc", "*.hpp")))
+    for f in files + [os.path.join(ROOT, "include", "mlmc_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _latest_pmc(config_key):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_config{}.json".format(config_key))))
@@ -624,30 +684,35 @@ def _latest_pmc(config_key):
         return json.load(f), os.path.basename(files[-1])
 
 
-def pmc_traffic(config_key, kname, launches_per_step):
-    """HBM bytes per accumulation launch from the most recent COMMITTED rocprofv3 PMC passes of this command
-    (profiles/rNN_pmc_config<k>.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; not measured in this run -- the file is
-    named in `traffic_source`).  FETCH_SIZE is in KB and, on gfx950, counts half of a coalesced streaming read (guide, HBM
-    section) -> read bytes = 2 * FETCH_SIZE * 1024.  The profiles hold per-dispatch averages per kernel instantiation;
-    the average over the dispatches of the matching kernels is returned.  None when no profile is committed."""
-    return pmc_avg_bytes_per_dispatch(config_key, kname)
+def pmc_traffic(config_key, kname):
+    """HBM bytes per accumulation launch.  Hardware counters cannot be read from inside this process: the figure comes from
+    the most recent COMMITTED rocprofv3 PMC passes of this command (profiles/rNN_pmc_config<k>.json: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs, tools/collect_profiles.sh) and is reported as `traffic_from_profile` with the file in
+    `traffic_source`.  It is promoted to `traffic` only when the profile was taken from THIS build (the profile records the
+    sha of the kernel sources, `csrc_sha`); a profile of older kernels leaves `traffic` null instead of going stale silently.
+    FETCH_SIZE is in KB and, on gfx950, counts half of a coalesced streaming read (guide, HBM section) -> read bytes =
+    2 * FETCH_SIZE * 1024; per-dispatch averages over the dispatches of the matching kernels."""
+    value, name, sha = pmc_avg_bytes_per_dispatch(config_key, kname)
+    same = value is not None and sha is not None and sha == csrc_sha()
+    return {"traffic": value if same else None, "traffic_from_profile": value, "traffic_source": name,
+            "traffic_profile_matches_build": bool(same)}
 
 
 def pmc_avg_bytes_per_dispatch(config_key, kname):
     prof, name = _latest_pmc(config_key)
     if prof is None:
-        return None, None
+        return None, None, None
     total = 0.0
     n_disp = 0
     for kn, e in prof.items():
-        if kname not in kn or "FETCH_SIZE_avg_per_dispatch" not in e:
+        if kn.startswith("_") or kname not in kn or "FETCH_SIZE_avg_per_dispatch" not in e:
             continue
         d = e.get("dispatches_fetch", 0)
         total += (2.0 * e["FETCH_SIZE_avg_per_dispatch"] + e.get("WRITE_SIZE_avg_per_dispatch", 0.0)) * 1024.0 * d
         n_disp += d
     if n_disp == 0:
-        return None, None
-    return int(total / n_disp), name
+        return None, None, None
+    return int(total / n_disp), name, (prof.get("_meta") or {}).get("csrc_sha")
 
 
 def cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_stats):
@@ -664,7 +729,11 @@ def cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_st
     b = onp.Basis(onp.SPLINE if cfg.get("basis") == "Spline" else onp.LEGENDRE, R, dom)
     if cfg.get("basis") == "Spline":
         n_s, chunk = 400_000, 50_000
-    host = [onp.synth_level_samples(l, n_s, steps, seed=4321) for l in range(L)]
+    # the first n_s samples of every level of the headline workload (rank 0, N = 1): the very bits the GPU step consumed
+    host = []
+    for l in range(L):
+        blocks = list(synth_level_host_blocks(l, 0, n_s, steps))
+        host.append((np.concatenate([b[1] for b in blocks]), None if l == 0 else np.concatenate([b[2] for b in blocks])))
     level_chunks = []
     for l, (f, c) in enumerate(host):
         cl = []
@@ -676,8 +745,8 @@ def cpu_baseline_and_parity(cfg, fn, dom, steps, onp, LevelAccumulator, level_st
     ref = onp.estimate_mean(level_chunks, lambda x: rows(b, x))
     cpu_s = time.perf_counter() - t0
     cpu = {"value": L * n_s * R / cpu_s, "unit": "moment-evals/s", "cores": 1, "kind": "port",
-           "sample": "{} levels x {} samples, Legendre R={}, {} estimate, NumPy restatement of the reference path "
-                     "(oracle/oracle_np.py), chunks of {}; {:.2f} s on 1 of {} host cores".format(
+           "sample": "the first {1} samples of each of the {0} levels of the headline workload, Legendre R={2}, {3} estimate, NumPy "
+                     "restatement of the reference path (oracle/oracle_np.py), chunks of {4}; {5:.2f} s on 1 of {6} host cores".format(
                          L, n_s, R, cfg["mode"], chunk, cpu_s, os.cpu_count()).replace("Legendre", cfg.get("basis", "Legendre"))}
     mode = LevelAccumulator.MOMENTS if cfg["mode"] == "moments" else LevelAccumulator.COV
     acc = LevelAccumulator(fn, L, mode)

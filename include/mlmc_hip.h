@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define MLMC_ABI_VERSION 3   /* 2: strides in mlmc_expr_eval, chaining flags, mlmc_accum_estimate_packed; 3: mlmc_wait_event */
+#define MLMC_ABI_VERSION 4   /* 2: strides in mlmc_expr_eval, chaining flags, mlmc_accum_estimate_packed; 3: mlmc_wait_event;
+                              * 4: x_lo / x_hi in mlmc_basis_desc, mlmc_expr_state, mlmc_accum_kernel_flops */
 
 /* basis kinds -- mlmc/moments.py: Legendre :174-229, Monomial :111-130, Fourier :133-171;
  * IDENTITY = the quantity itself (estimate_mean of a plain quantity, quantity_estimate.py:22-80);
@@ -50,7 +51,13 @@ typedef struct mlmc_accum mlmc_accum;
 /* Plain-data image of a reference Moments object (mlmc/moments.py:10-39):
  * t = (x - shift) * scale + ref0 (after log(x) if is_log); values with t outside [ref0, ref1]
  * are NaN-masked when is_clip (Moments.clip, moments.py:58-67).  `matrix` (row-major
- * [out_size][size], host pointer, may be NULL) is TransformedMoments._transform (moments.py:232-259). */
+ * [out_size][size], host pointer, may be NULL) is TransformedMoments._transform (moments.py:232-259).
+ * x_lo / x_hi (used when is_log and is_clip): the keep / drop decision of a sample under log=True is taken on the RAW
+ * value, keep <=> x_lo <= x <= x_hi, where x_lo is the smallest and x_hi the largest double whose
+ * t = (log(x) - shift) * scale + ref0, computed with the CALLER's log, lies in [ref0, ref1].  The map x -> t is monotone,
+ * so the caller finds both by bisection over the doubles (<= 64 steps each); sample counts are then bit-identical to the
+ * caller's own NumPy / libm path, whatever the last bit of the device's log is (moments.py:27-39,58-73 use np.log).
+ * x_lo == x_hi == 0 asks the library to bisect with the C library's log() of the host. */
 typedef struct {
     int32_t kind;
     int32_t size;       /* number of basis functions R of the underlying family */
@@ -62,6 +69,7 @@ typedef struct {
     int32_t out_size;   /* rows of `matrix`; 0 = no linear transform */
     int32_t reserved;
     const double *matrix;
+    double x_lo, x_hi;  /* raw-value keep interval under is_log && is_clip (see above) */
 } mlmc_basis_desc;
 
 /* ---- runtime -------------------------------------------------------------------------- */
@@ -136,6 +144,13 @@ int mlmc_accum_finalize_packed(mlmc_accum *a, double *packed, int mem_kind);
  * call of this function (it returns the totals and clears them; mlmc_accum_reset leaves them alone; needs
  * mlmc_init flag bit0); also the algorithmic HBM bytes those launches had to read.  Waits for the last launch. */
 int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes);
+/* Matrix-core flops the covariance launches counted by mlmc_accum_kernel_time have EXECUTED since create or since the
+ * previous call of this function: one v_mfma_f64_16x16x4_f64 is 2 * 16 * 16 * 4 flops and covers four samples, i.e. 512
+ * flops per 16 x 16 output tile and sample, times the tiles the kernels' tile lists name.  Symmetric Gram tiles are computed
+ * once (R = 64, pair level, mean + variance: 16 + 16 + 10 = 42 tiles instead of 48), so the figure is BELOW the reference-
+ * form count 6 R^2 per pair (quantity_estimate.py:131-147); it is the numerator of a physical matrix-pipe fraction.
+ * Returns the total and clears it. */
+int mlmc_accum_kernel_flops(mlmc_accum *a, int64_t *mfma_flops);
 
 /* ---- maximum-entropy density (mlmc/tool/simple_distribution.py:9-327) ------------------ */
 typedef struct {
@@ -234,6 +249,12 @@ void mlmc_expr_destroy(mlmc_expr *e);
  * synchronises only when the program selects. */
 int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coarse, int64_t n, int64_t sample_stride,
                    int64_t side_stride, double *fine_out, double *coarse_out, int64_t *n_selected);
+/* Which form evaluates this program: *state = 0 the byte-code interpreter (the program has not reached its compile threshold
+ * yet), 2 its own compiled kernel (hiprtc, gfx950), -1 no compiled form (hiprtc missing, compile or load error: the
+ * interpreter keeps the program), -2 compiled forms are not applicable (program too long); *compiled_launches = evaluations of
+ * THIS handle that ran the compiled kernel.  Either pointer may be NULL.  (MLMC_EXPR_JIT=0 keeps the interpreter,
+ * MLMC_EXPR_JIT_AFTER=k compiles at the (k+1)-th evaluation, MLMC_EXPR_JIT_VERBOSE=1 prints the hiprtc log on failure.) */
+int mlmc_expr_state(mlmc_expr *e, int32_t *state, int64_t *compiled_launches);
 /* HIP-event time (ms), launches and algorithmic bytes (8 B per value of every referenced stored row and every result
  * row) of the evaluation kernel since create or the previous call; same contract as mlmc_accum_kernel_time. */
 int mlmc_expr_kernel_time(mlmc_expr *e, double *ms, int64_t *launches, int64_t *alg_bytes);

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLMC_HIP_LIB", os.path.join(_HERE, "libmlmc_hip.so"))   # env override: development builds
 
-ABI_VERSION = 3      # MLMC_ABI_VERSION of include/mlmc_hip.h
+ABI_VERSION = 4      # MLMC_ABI_VERSION of include/mlmc_hip.h
 LEGENDRE, MONOMIAL, FOURIER, IDENTITY, SPLINE = 0, 1, 2, 3, 4
 MODE_MOMENTS, MODE_COV = 0, 1
 MODE_MEAN_ONLY = 0x100
@@ -27,7 +27,8 @@ class MlmcHipError(RuntimeError):
 class BasisDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("size", C.c_int32), ("shift", C.c_double), ("scale", C.c_double),
                 ("ref0", C.c_double), ("ref1", C.c_double), ("is_log", C.c_int32), ("is_clip", C.c_int32),
-                ("out_size", C.c_int32), ("reserved", C.c_int32), ("matrix", C.POINTER(C.c_double))]
+                ("out_size", C.c_int32), ("reserved", C.c_int32), ("matrix", C.POINTER(C.c_double)),
+                ("x_lo", C.c_double), ("x_hi", C.c_double)]
 
 
 class MaxentOpts(C.Structure):
@@ -67,6 +68,7 @@ SIGNATURES = {
     "mlmc_accum_estimate": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "mlmc_accum_estimate_packed": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "mlmc_accum_kernel_time": (C.c_int, [_vp, _dp, _ip, _ip]),
+    "mlmc_accum_kernel_flops": (C.c_int, [_vp, _ip]),
     "mlmc_percentiles": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _ip, C.c_int]),
     "mlmc_maxent_solve": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.POINTER(MaxentOpts), _vp,
                                     C.c_int32, _vp, _vp, _vp, C.POINTER(MaxentInfo)]),
@@ -75,6 +77,7 @@ SIGNATURES = {
     "mlmc_expr_create": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "mlmc_expr_destroy": (None, [_vp]),
     "mlmc_expr_eval": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _ip]),
+    "mlmc_expr_state": (C.c_int, [_vp, C.POINTER(C.c_int32), _ip]),
     "mlmc_expr_kernel_time": (C.c_int, [_vp, _dp, _ip, _ip]),
     "mlmc_synth_generate": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                       C.c_int32, _vp, _vp]),

@@ -24,6 +24,16 @@ std::recursive_mutex &api_mutex() {
     return m;
 }
 
+void bind_thread_to_device() {
+    static thread_local int bound = -1;
+    const Runtime &r = rt();
+    if (r.ready && bound != r.device) {
+        if (hipSetDevice(r.device) == hipSuccess) bound = r.device;
+    } else if (!r.ready) {
+        bound = -1;           // mlmc_shutdown / a later mlmc_init may bind another device
+    }
+}
+
 int ensure(void **p, size_t *cap, size_t bytes) {
     if (bytes <= *cap && *p) return 0;
     if (*p) {
@@ -70,6 +80,42 @@ static int timing_collect(mlmc_accum *a) {
     }
     a->ev_used = 0;
     return 0;
+}
+
+// Raw-value keep interval of a log-domain basis (mlmc_hip.h, mlmc_basis_desc): the smallest / largest positive double whose
+// t = (log(x) - shift) * scale + ref0 lies in [ref0, ref1], by bisection over the bit patterns of the positive doubles
+// (ordered like the values) with the host C library's log.  Nothing kept: (inf, 0).
+static void log_keep_interval(const BasisParams &p, double *x_lo, double *x_hi) {
+    auto t_of = [&](uint64_t bits) {
+        double x;
+        std::memcpy(&x, &bits, sizeof x);
+        volatile double v = std::log(x);          // volatile: two roundings like NumPy, whatever the host compiler contracts
+        volatile double w = (v - p.shift) * p.scale;
+        return (double)(w + p.ref0);
+    };
+    auto as_double = [](uint64_t bits) { double x; std::memcpy(&x, &bits, sizeof x); return x; };
+    const uint64_t top = 0x7ff0000000000000ull;   // +inf; bit patterns 1 .. top - 1 are the positive finite doubles
+    // first x with t >= ref0 (predicate false ... false true ... true)
+    uint64_t lo = 1, hi = top;
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (t_of(mid) >= p.ref0) hi = mid; else lo = mid + 1;
+    }
+    const uint64_t first = lo;
+    // last x with t <= ref1 (true ... true false ... false)
+    lo = 0; hi = top - 1;
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (t_of(mid) <= p.ref1) lo = mid; else hi = mid - 1;
+    }
+    const uint64_t last = lo;
+    if (first >= top || last == 0 || first > last) {
+        *x_lo = HUGE_VAL;
+        *x_hi = 0.0;
+        return;
+    }
+    *x_lo = as_double(first);
+    *x_hi = as_double(last);
 }
 
 static int need_runtime() {
@@ -200,6 +246,9 @@ int mlmc_basis_create(const mlmc_basis_desc *d, mlmc_basis **out) {
     b->p.ref1 = d->ref1;
     b->p.is_log = d->is_log;
     b->p.is_clip = d->is_clip;
+    b->p.x_lo = d->x_lo;
+    b->p.x_hi = d->x_hi;
+    if (d->is_log && d->is_clip && d->x_lo == 0.0 && d->x_hi == 0.0) log_keep_interval(b->p, &b->p.x_lo, &b->p.x_hi);
     b->out_size = d->out_size;
     const int R = d->size;
     b->scale_c.assign(R, 1.0);
@@ -550,6 +599,14 @@ int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t
     a->ms_total = 0;
     a->launches = 0;
     a->alg_bytes = 0;
+    return 0;
+}
+
+int mlmc_accum_kernel_flops(mlmc_accum *a, int64_t *mfma_flops) {
+    MLMC_API_GUARD;
+    if (!a) return fail("mlmc_accum_kernel_flops: null argument");
+    if (mfma_flops) *mfma_flops = a->mfma_flops;
+    a->mfma_flops = 0;
     return 0;
 }
 

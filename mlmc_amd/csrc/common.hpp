@@ -33,7 +33,16 @@ int fail(const std::string &msg);
 // the one-call forms (mlmc_accum_estimate, ...) go through other entry points.  Every extern "C" function that touches the
 // device takes it first (MLMC_API_GUARD); mlmc_last_error is thread-local and needs none.
 std::recursive_mutex &api_mutex();
-#define MLMC_API_GUARD std::lock_guard<std::recursive_mutex> mlmc_api_guard_(::mlmc::api_mutex())
+// HIP's current device is a property of the calling host thread (default 0), while the library's stream, scratch and
+// modules live on the device mlmc_init bound: every entry point re-binds the calling thread (a thread-local store, no
+// driver call when it is already current), so worker threads of a rank with LOCAL_RANK > 0 allocate and launch on the
+// right GPU.
+void bind_thread_to_device();
+struct ApiGuard {
+    std::lock_guard<std::recursive_mutex> lock;
+    ApiGuard() : lock(api_mutex()) { bind_thread_to_device(); }
+};
+#define MLMC_API_GUARD ::mlmc::ApiGuard mlmc_api_guard_
 
 struct Runtime {
     bool ready = false;
@@ -55,6 +64,7 @@ struct BasisParams {
     int size;      // R of the underlying family
     double shift, scale, ref0, ref1;
     int is_log, is_clip;
+    double x_lo, x_hi;   // is_log && is_clip: keep <=> x_lo <= x <= x_hi on the raw value (host-bisected, mlmc_hip.h)
 };
 
 }  // namespace mlmc
@@ -110,6 +120,7 @@ struct mlmc_accum {
     size_t ev_used = 0;
     double ms_total = 0;
     int64_t launches = 0, alg_bytes = 0;
+    int64_t mfma_flops = 0;   // executed matrix-core flops of the timed covariance launches (mlmc_accum_kernel_flops)
     int RP = 0;  // COV: R padded to 16
     std::vector<PendingSeg> pending;   // MOMENTS: chunks gathered into one launch (flushed by finalize / conflicts)
 };

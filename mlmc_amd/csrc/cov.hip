@@ -840,6 +840,17 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
     return 0;
 }
 
+// 16 x 16 output tiles one sample (pair) contributes to in one block launch -- the kernels' tile lists above:
+// gram_mode 0 = G0, G1, G2 (level 0: two symmetric matrices), 1 = D^T D (symmetric), 2 = G0 only (level 0: F^T F, symmetric).
+// x 512 = executed matrix-core flops per sample (mlmc_accum_kernel_flops).
+static int cov_tiles_per_sample(int T, bool diagonal, bool pair, int gram_mode) {
+    const int full = T * T, upper = T * (T + 1) / 2;
+    if (!diagonal) return (gram_mode == 0 ? (pair ? 3 : 2) : 1) * full;      // two term windows: no symmetry inside the block
+    if (gram_mode == 0) return pair ? 2 * full + upper : 2 * upper;
+    if (gram_mode == 1 || !pair) return upper;
+    return full;
+}
+
 int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
                      int64_t n, bool count, int gram_mode, int ncomp) {
     // ncomp > 1: components comp .. comp + ncomp - 1 of a vector quantity ([M][n] arrays) in ONE launch (grid.y)
@@ -892,6 +903,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
                 if (int rc2 = timing_end(a)) return rc2;
                 a->launches += 1;
                 a->alg_bytes += (int64_t)n * (pair ? 16 : 8) * ncomp;
+                a->mfma_flops += (int64_t)512 * cov_tiles_per_sample(T, bi == bj, pair, gram_mode) * n * ncomp;
             }
             hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16), ncomp), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, NG,
                                a->RP, 64 * bi, 64 * bj, totals, a->int_width, (!pair && bi != bj) ? 1 : 0);

@@ -16,8 +16,19 @@ __device__ __forceinline__ double transform_value(const BasisParams &bp, double 
         keep = !(x != x);
         return x;
     }
-    double v = bp.is_log ? log(x) : x;
-    double t = (v - bp.shift) * bp.scale + bp.ref0;   // two roundings, no contraction
+    if (bp.is_log) {
+        // The reference decides on t computed with NumPy's log (moments.py:27-39); the device log may differ from it in the
+        // last bit, which would flip a sample that sits on the edge of the domain.  The decision is therefore taken on the
+        // raw value against thresholds the host has bisected with its own log (x -> t is monotone); the device log only
+        // supplies the VALUE of t (1 ulp of it is far inside the 1e-10 value tolerance).
+        const double tl = (log(x) - bp.shift) * bp.scale + bp.ref0;
+        if (bp.is_clip)
+            keep = (x >= bp.x_lo) && (x <= bp.x_hi);                 // NaN -> false
+        else
+            keep = (x > 0.0) && (x < __builtin_inf()) && !(tl != tl) && !(fabs(tl) == __builtin_inf());
+        return tl;
+    }
+    double t = (x - bp.shift) * bp.scale + bp.ref0;   // two roundings, no contraction
     if (bp.is_clip)
         keep = (t >= bp.ref0) && (t <= bp.ref1);      // NaN -> false
     else

@@ -37,6 +37,7 @@ struct mlmc_expr {
     size_t ev_used = 0;
     double ms_total = 0;
     int64_t launches = 0, alg_bytes = 0;
+    int64_t jit_launches = 0;             // evaluations that ran the compiled kernel (mlmc_expr_state)
 };
 
 static int expr_timing_collect(mlmc_expr *e) {
@@ -425,7 +426,7 @@ int mlmc_expr_create(const mlmc_expr_instr *prog, int32_t n_instr, int32_t n_reg
     e->n_out = n_out_rows;
     e->selects = selects;
     e->heavy = heavy;
-    e->jit = expr_jit_lookup(e->prog, n_regs);
+    e->jit = expr_jit_lookup(e->prog, n_regs, n_in_rows);
     if (hipMalloc(&e->d_prog, sizeof(mlmc_expr_instr) * n_instr) != hipSuccess ||
         hipMalloc(&e->d_rows, sizeof(double *) * n_in_rows) != hipSuccess ||
         hipHostMalloc(&e->h_total, sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
@@ -528,6 +529,7 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
     if (e->jit && expr_jit_ready(*e->jit)) {
         // the program's own kernel (expr_jit.hip): registers are locals, no LDS, no decode; same rows bit for bit
         if (int rc = expr_jit_launch(*e->jit, has_coarse != 0, &tab, d_rows, n, sample_stride, side_stride, tf, tc, keep, st)) return rc;
+        e->jit_launches += 1;
     } else if (has_coarse) {
         if (e->heavy) MLMC_X_LAUNCH_S(true, true); else MLMC_X_LAUNCH_S(true, false);
     } else {
@@ -550,6 +552,14 @@ int mlmc_expr_eval(mlmc_expr *e, const double *const *rows_in, int32_t has_coars
     MLMC_HIP_CHECK(hipGetLastError());
     MLMC_HIP_CHECK(wait_stream(st));
     if (n_selected) *n_selected = *e->h_total;
+    return 0;
+}
+
+int mlmc_expr_state(mlmc_expr *e, int32_t *state, int64_t *compiled_launches) {
+    MLMC_API_GUARD;
+    if (!e) return fail("mlmc_expr_state: null argument");
+    if (state) *state = e->jit ? e->jit->state : -2;
+    if (compiled_launches) *compiled_launches = e->jit_launches;
     return 0;
 }
 

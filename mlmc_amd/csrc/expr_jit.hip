@@ -210,11 +210,11 @@ extern "C" __global__ __launch_bounds__(256) void k_single(RowTable tab, const d
 }
 )";
 
-std::string generate(const std::vector<mlmc_expr_instr> &prog, int n_regs) {
+std::string generate(const std::vector<mlmc_expr_instr> &prog, int n_regs, int n_in) {
     std::string s = PRELUDE;
-    bool use_table = true;
-    for (const mlmc_expr_instr &in : prog)
-        if ((in.op & MLMC_X_OP_MASK) == MLMC_X_LOAD && in.a >= 64) use_table = false;
+    // the same rule as mlmc_expr_eval (expr.hip): up to 64 stored rows the pointers are passed by value in `tab`, beyond
+    // that `tab` is zero and they come through `rows` -- decided by the program's row count, not by the rows it loads
+    const bool use_table = n_in <= 64;
     for (int r = 0; r < n_regs; ++r) s += "    double r" + std::to_string(r) + "[V];\n";
     for (const mlmc_expr_instr &in : prog) {
         const int op = in.op & MLMC_X_OP_MASK;
@@ -284,16 +284,18 @@ int jit_threshold() {
 
 }  // namespace
 
-std::shared_ptr<ExprJit> expr_jit_lookup(const std::vector<mlmc_expr_instr> &prog, int n_regs) {
+std::shared_ptr<ExprJit> expr_jit_lookup(const std::vector<mlmc_expr_instr> &prog, int n_regs, int n_in_rows) {
     if (prog.size() > 512) return nullptr;
     std::string key((const char *)prog.data(), prog.size() * sizeof(mlmc_expr_instr));
     key.push_back((char)n_regs);
+    key.push_back(n_in_rows <= 64 ? 't' : 'r');    // where the generated code reads the row pointers from
     auto &c = cache();
     auto it = c.find(key);
     if (it != c.end()) return it->second;
     auto e = std::make_shared<ExprJit>();
     e->prog = prog;
     e->n_regs = n_regs;
+    e->n_in = n_in_rows;
     c.emplace(std::move(key), e);
     return e;
 }
@@ -307,7 +309,7 @@ bool expr_jit_ready(ExprJit &j) {
     j.state = -1;                       // whatever fails below: the interpreter keeps the program
     const Rtc &r = rtc();
     if (!r.ok) return false;
-    const std::string src = generate(j.prog, j.n_regs);
+    const std::string src = generate(j.prog, j.n_regs, j.n_in);
     if (src.empty()) return false;
     Rtc::Program prog = nullptr;
     if (r.create(&prog, src.c_str(), "mlmc_expr_jit.hip", 0, nullptr, nullptr) != 0) return false;

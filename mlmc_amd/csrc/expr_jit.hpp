@@ -13,6 +13,7 @@ namespace mlmc {
 struct ExprJit {
     std::vector<mlmc_expr_instr> prog;
     int n_regs = 0;
+    int n_in = 0;                  // stored rows of the program: <= 64 -> the row pointers arrive by value (RowTable), else through `rows`
     int uses = 0;
     int state = 0;                 // 0: not compiled yet, 2: module loaded, -1: no compiled form (hiprtc missing / error)
     std::vector<char> code;
@@ -21,7 +22,7 @@ struct ExprJit {
 };
 
 // Entry of the process-wide cache for this program (nullptr: compiled forms are switched off or the program is too long).
-std::shared_ptr<ExprJit> expr_jit_lookup(const std::vector<mlmc_expr_instr> &prog, int n_regs);
+std::shared_ptr<ExprJit> expr_jit_lookup(const std::vector<mlmc_expr_instr> &prog, int n_regs, int n_in_rows);
 // Count one evaluation; compile when the threshold is reached.  true: the compiled kernel can be launched.
 bool expr_jit_ready(ExprJit &j);
 // tab_bytes: the 64 row pointers passed by value (RowTable of expr.hip).

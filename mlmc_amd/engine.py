@@ -178,6 +178,13 @@ class LevelAccumulator:
         _lib.check(_lib.lib().mlmc_accum_kernel_time(self._h, C.byref(ms), C.byref(launches), C.byref(nbytes)))
         return ms.value, launches.value, nbytes.value
 
+    def kernel_flops(self):
+        """Matrix-core flops the timed covariance launches executed since create or the previous call (symmetric Gram tiles
+        counted once: `mlmc_accum_kernel_flops`); returns and clears the total."""
+        fl = C.c_int64()
+        _lib.check(_lib.lib().mlmc_accum_kernel_flops(self._h, C.byref(fl)))
+        return fl.value
+
 
 def allreduce_partials(packed, group=None):
     """The only exchange step of the path: ONE all-reduce (sum) of the packed fp64 partials

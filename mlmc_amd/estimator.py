@@ -44,7 +44,7 @@ class Estimate:
         if moments_fn is None:
             moments_fn = self._moments_fn
         r = qe.estimate_mean(qe.covariance(self._quantity, moments_fn))
-        self._cov_memo = (self._memo_key(moments_fn), r, moments_fn)
+        self._cov_memo = (self._memo_key(moments_fn), r, moments_fn, self._quantity)
         return r.mean, r.var
 
     def _memo_key(self, moments_fn):
@@ -54,18 +54,20 @@ class Estimate:
             stamps = qe._level_stamps(self._quantity.get_quantity_storage())
         except Exception:
             return None
-        return (id(self._quantity), id(moments_fn), stamps, qe.device_cache_generation())
+        return (stamps, qe.device_cache_generation())
 
     def _diff_vars_from_covariance(self, moments_fn):
         """Level sums of the moments out of the last covariance estimate of the same (quantity, moments_fn, samples):
         row 0 of the covariance rows is phi_0 phi_j = phi_j, so its level means / variances ARE those of the moments
         (engine.moments_from_covariance) -- no second pass over the samples.  None when no such estimate is at hand."""
         memo = getattr(self, "_cov_memo", None)
-        if memo is None or memo[0] is None or memo[0] != self._memo_key(moments_fn) or memo[2] is not moments_fn:
+        # the memo holds the quantity and the moment functions themselves (compared with `is`: an id() can be reused)
+        if memo is None or memo[0] is None or memo[0] != self._memo_key(moments_fn) or memo[2] is not moments_fn \
+                or memo[3] is not self._quantity:
             return None
-        from .moments import TransformedMoments
-        if isinstance(moments_fn, TransformedMoments):          # the first transformed moment need not be the constant
-            return None
+        from .moments import Legendre, Monomial, Fourier, Spline
+        if type(moments_fn) not in (Legendre, Monomial, Fourier, Spline):
+            return None          # only the families known to start with the constant: phi_0 = 1 (moments.py:122-126,145-162,195-197)
         r, size = memo[1], moments_fn.size
         n_levels = r._l_means.shape[0]
         n_comp = r._l_means.shape[1] // (size * size)

@@ -13,6 +13,45 @@ import numpy as np
 from . import _lib
 
 
+def log_keep_interval(shift, scale, ref0, ref1):
+    """Raw-value keep interval of a log-domain moments object with safe_eval: (x_lo, x_hi) = the smallest / largest positive
+    double x whose t = (np.log(x) - shift) * scale + ref0 -- exactly the reference's arithmetic, moments.py:27-39,69-70 --
+    lies in [ref0, ref1] (Moments.clip keeps the closed interval, moments.py:58-67).  x -> t is monotone, so both ends are
+    found by bisection over the bit patterns of the positive doubles (ordered like the values), <= 64 evaluations of
+    NumPy's own log each.  The device then compares the RAW sample value with these thresholds (mlmc_basis_desc.x_lo /
+    x_hi), so the sample counts equal the NumPy path's bit for bit whatever the last bit of the device's log is.
+    Nothing kept: (inf, 0)."""
+    shift, scale, ref0, ref1 = (np.float64(v) for v in (shift, scale, ref0, ref1))
+    buf = np.empty(1, dtype=np.uint64)
+
+    def t_of(bits):
+        buf[0] = bits
+        with np.errstate(all="ignore"):
+            return ((np.log(buf.view(np.float64)) - shift) * scale + ref0)[0]      # array arithmetic, like the reference
+
+    top = 0x7ff0000000000000                  # +inf; 1 .. top - 1 are the positive finite doubles
+    lo, hi = 1, top
+    while lo < hi:                            # first x with t >= ref0
+        mid = lo + (hi - lo) // 2
+        if t_of(mid) >= ref0:
+            hi = mid
+        else:
+            lo = mid + 1
+    first = lo
+    lo, hi = 0, top - 1
+    while lo < hi:                            # last x with t <= ref1
+        mid = lo + (hi - lo + 1) // 2
+        if t_of(mid) <= ref1:
+            lo = mid
+        else:
+            hi = mid - 1
+    last = lo
+    if first >= top or last == 0 or first > last:
+        return float("inf"), 0.0
+    pair = np.array([first, last], dtype=np.uint64).view(np.float64)
+    return float(pair[0]), float(pair[1])
+
+
 class Moments:
     """Base class: domain transform parameters + device handle (reference: moments.py:6-108)."""
     _kind = None
@@ -46,6 +85,11 @@ class Moments:
         d.is_clip = int(bool(self._is_clip))
         d.out_size = 0
         d.matrix = None
+        d.x_lo, d.x_hi = 0.0, 0.0
+        if self._is_log and self._is_clip:
+            if getattr(self, "_log_keep", None) is None:
+                self._log_keep = log_keep_interval(d.shift, d.scale, d.ref0, d.ref1)
+            d.x_lo, d.x_hi = self._log_keep
         if matrix is not None:
             d.out_size = int(matrix.shape[0])
             d.matrix = matrix.ctypes.data_as(C.POINTER(C.c_double))
@@ -164,6 +208,11 @@ class Fourier(Moments):
 
     def change_size(self, size):
         return Fourier(size, self.domain, ref_domain=self.ref_domain, log=self._is_log, safe_eval=self._is_clip)
+
+    def _eval_all(self, value, size):
+        out = super()._eval_all(value, size)
+        out[..., 0] = 1         # the reference fills column 0 with the constant, also in rows of masked values (moments.py:156)
+        return out
 
     def eval(self, i, value):
         # the reference's Fourier.eval (:164-171) disagrees with its own _eval_all; column i of eval_all is the truth

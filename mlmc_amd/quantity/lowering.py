@@ -390,6 +390,15 @@ class DevicePlan:
         _lib.check(_lib.lib().mlmc_expr_kernel_time(self.handle(), C.byref(ms), C.byref(launches), C.byref(nbytes)))
         return ms.value, launches.value, nbytes.value
 
+    JIT_STATES = {0: "interpreter", 2: "compiled", -1: "failed", -2: "not applicable"}
+
+    def jit_state(self):
+        """(which form evaluates the program -- "interpreter" | "compiled" | "failed" | "not applicable" --, evaluations of this
+        handle that ran the compiled kernel): `mlmc_expr_state`."""
+        state, count = C.c_int32(), C.c_int64()
+        _lib.check(_lib.lib().mlmc_expr_state(self.handle(), C.byref(state), C.byref(count)))
+        return self.JIT_STATES.get(state.value, str(state.value)), count.value
+
     def __del__(self):
         try:
             if self._handle is not None and _lib._lib is not None:

@@ -98,32 +98,37 @@ class _DeviceChunkCache:
         self._bytes = 0
         self.uploads = 0
         self.hits = 0
+        # Every method is a multi-step update of (_items, _bytes): `get` alone is lookup + move_to_end, and a clear() of another
+        # thread between the two raises KeyError in the looking thread (the round-2 "hang" of
+        # test_concurrent_estimates_through_the_python_api).  Callers hold _estimate_lock as well; the
+        # cache does not rely on that.
+        self._lock = threading.RLock()
 
     @staticmethod
     def budget():
         return int(float(os.environ.get("MLMC_HIP_DEVICE_CACHE_GB", "64")) * 2 ** 30)
 
     def get(self, key):
-        item = self._items.get(key)
-        if item is not None:
-            self._items.move_to_end(key)
-            self.hits += 1
-        return item
+        with self._lock:
+            item = self._items.get(key)
+            if item is not None:
+                self._items.move_to_end(key)
+                self.hits += 1
+            return item
+
+    def __contains__(self, key):
+        with self._lock:
+            return key in self._items
 
     def put(self, key, fine, coarse, owner=None):
-        import torch
         nbytes = fine.nbytes + (0 if coarse is None else coarse.nbytes)
         if nbytes > self.budget():
             return None
-        self.drop(key)
-        while self._bytes + nbytes > self.budget() and self._items:
-            _, (_, _, old, _) = self._items.popitem(last=False)
-            self._bytes -= old
         # `owner` (the source quantity) is kept alive with the entry, so its id() in the key cannot be re-used
         item = (_upload(fine, count=False), None if coarse is None else _upload(coarse, count=False), nbytes, owner)
-        self._items[key] = item
-        self._bytes += nbytes
-        self.uploads += 1
+        with self._lock:
+            self._insert(key, item, nbytes)
+            self.uploads += 1
         return item
 
     def put_tensors(self, key, fine, coarse, owner=None):
@@ -132,26 +137,33 @@ class _DeviceChunkCache:
         item = (fine, coarse, nbytes, owner)
         if nbytes > self.budget():
             return item
+        with self._lock:
+            self._insert(key, item, nbytes)
+        return item
+
+    def _insert(self, key, item, nbytes):
         self.drop(key)                                   # a replaced entry gives its bytes back first
         while self._bytes + nbytes > self.budget() and self._items:
             _, (_, _, old, _) = self._items.popitem(last=False)
             self._bytes -= old
         self._items[key] = item
         self._bytes += nbytes
-        return item
 
     def drop(self, key):
-        item = self._items.pop(key, None)
-        if item is not None:
-            self._bytes -= item[2]
+        with self._lock:
+            item = self._items.pop(key, None)
+            if item is not None:
+                self._bytes -= item[2]
 
     def drop_owner(self, owner):
-        for key in [k for k, item in self._items.items() if item[3] is owner]:
-            self.drop(key)
+        with self._lock:
+            for key in [k for k, item in self._items.items() if item[3] is owner]:
+                self.drop(key)
 
     def clear(self):
-        self._items.clear()
-        self._bytes = 0
+        with self._lock:
+            self._items.clear()
+            self._bytes = 0
 
 
 def _lib_device():
@@ -188,6 +200,7 @@ def device_cache_drop_owner(storage):
     """Drop the resident chunks that came from one storage (it changed: grew, was refilled)."""
     with _estimate_lock:
         _device_cache.drop_owner(storage)
+        _block_meta.drop_owner(storage)
 
 
 class _StagingRing:
@@ -363,12 +376,19 @@ def _device_tree_enabled():
     return os.environ.get("MLMC_HIP_DEVICE_TREE", "1") != "0"
 
 
+def _owner_of(plan):
+    """The object whose lifetime bounds the resident rows / blocks of a lowered tree: the storage behind the leaf, or the
+    leaf itself when it has none.  ONE rule for the upload paths, the residency check of the prefetcher and the cache keys."""
+    storage = getattr(plan.leaf, "_storage", None)
+    return storage if storage is not None else plan.leaf
+
+
 def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache, raw=None):
     """One stored row of one chunk as a device tensor in the storage's own layout: interleaved (fine, coarse) pairs
     [n, 2], or [n, 1] at level 0.  Uploaded once per (storage, chunk, row) and shared by every quantity that reads it."""
     import torch
     storage = getattr(plan.leaf, "_storage", None)
-    owner = storage if storage is not None else plan.leaf
+    owner = _owner_of(plan)
     key = ("row", id(owner)) + chunk_key + (stored_row,)
     item = _device_cache.get(key) if use_cache else None
     if item is not None:
@@ -408,9 +428,53 @@ def _block_layout(raw, n_rows_read):
     return span, sn, sw
 
 
-# (block key, rows the tree reads) -> (sample stride, side stride, n, width) of a resident block, or None when the chunk is
-# uploaded row by row: a later estimate decides without reading the chunk from the storage again
-_block_meta = {}
+class _BlockMeta:
+    """(block key [, rows the tree reads]) -> (sample stride, side stride, n, width) of a resident block, or None when the
+    chunk is uploaded row by row: a later estimate decides without reading the chunk from the storage again.  The keys
+    carry id(owner); every entry also holds a weak reference to that owner and counts only while it is the same live
+    object -- a new storage that happens to get the id of a freed one inherits nothing."""
+    _MISSING = object()
+
+    def __init__(self):
+        self._d = {}
+
+    @staticmethod
+    def _ref(owner):
+        import weakref
+        try:
+            return weakref.ref(owner)
+        except TypeError:                     # not weak-referenceable: keep it alive, its id then stays unique
+            return lambda owner=owner: owner
+
+    def get(self, key, owner, default=_MISSING):
+        entry = self._d.get(key)
+        if entry is None or entry[0]() is not owner:
+            if entry is not None:
+                del self._d[key]
+            return default
+        return entry[1]
+
+    def has(self, key, owner):
+        return self.get(key, owner) is not self._MISSING
+
+    def put(self, key, owner, value):
+        if len(self._d) > 65536:
+            self._d.clear()
+        self._d[key] = (self._ref(owner), value)
+
+    def drop_owner(self, owner):
+        oid = id(owner)
+        for key in [k for k in self._d if k[1] == oid]:
+            del self._d[key]
+
+    def clear(self):
+        self._d.clear()
+
+    def __len__(self):
+        return len(self._d)
+
+
+_block_meta = _BlockMeta()
 
 
 def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache, raw=None):
@@ -425,20 +489,20 @@ def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache, raw=None):
     storage = getattr(plan.leaf, "_storage", None)
     if hasattr(storage, "device_row") or os.environ.get("MLMC_HIP_BLOCK_UPLOAD", "1") == "0":
         return None
-    owner = storage if storage is not None else plan.leaf
+    owner = _owner_of(plan)
     key = ("block", id(owner)) + chunk_key
     item = _device_cache.get(key) if use_cache else None
-    if use_cache and (key + ("any",) in _block_meta or key + (len(plan.in_rows),) in _block_meta):
+    if use_cache and (_block_meta.has(key + ("any",), owner) or _block_meta.has(key + (len(plan.in_rows),), owner)):
         return None                                               # known: the chunk goes up row by row (for any / this many rows)
-    if item is not None and key in _block_meta:
-        return (item[0],) + _block_meta[key]                      # a resident block serves every tree
+    if item is not None and _block_meta.has(key, owner):
+        return (item[0],) + _block_meta.get(key, owner)           # a resident block serves every tree
     if raw is None:
         raw = plan.leaf.samples(chunk_spec)                       # [M_stored, n, 2|1] view of the storage / fresh read
     layout = _block_layout(raw, len(plan.in_rows))
     if layout is None or layout[0] * 8 > _DeviceChunkCache.budget() // 4:
         if use_cache:                                             # not a record array at all, or too few of its rows are read
             intrinsic = layout is not None or _block_layout(raw, raw.shape[0]) is None
-            _block_meta[key + (("any",) if intrinsic else (len(plan.in_rows),))] = None
+            _block_meta.put(key + (("any",) if intrinsic else (len(plan.in_rows),)), owner, None)
         return None
     span, sn, sw = layout
     m_total, n, width = raw.shape
@@ -447,9 +511,7 @@ def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache, raw=None):
         t = _upload(flat)
         if use_cache:
             _device_cache.put_tensors(key, t, None, owner=owner)
-            if len(_block_meta) > 65536:
-                _block_meta.clear()
-            _block_meta[key] = (sn, sw, n, width)
+            _block_meta.put(key, owner, (sn, sw, n, width))
     else:
         t = item[0]
     return t, sn, sw, n, width
@@ -467,8 +529,8 @@ def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache, raw=None):
         return fine, coarse
     storage = getattr(plan.leaf, "_storage", None)
     if raw is None and not hasattr(storage, "device_row"):
-        owner = storage if storage is not None else plan.leaf
-        if not use_cache or any(("row", id(owner)) + chunk_key + (r,) not in _device_cache._items for r in plan.in_rows):
+        owner = _owner_of(plan)
+        if not use_cache or any(("row", id(owner)) + chunk_key + (r,) not in _device_cache for r in plan.in_rows):
             raw = plan.leaf.samples(chunk_spec)                  # ONE read of the chunk for all its rows
     rows = [_stored_row_on_device(plan, chunk_spec, chunk_key, r, use_cache, raw) for r in plan.in_rows]
     n, width = rows[0].shape
@@ -485,7 +547,7 @@ def _cache_ident(source, plan):
     trees (rebuilt quantity objects, a second make_root_quantity over the same storage) share entries -- else the
     quantity object itself."""
     if plan is not None:
-        return (id(getattr(plan.leaf, "_storage", plan.leaf)), plan.signature)
+        return (id(_owner_of(plan)), plan.signature)
     return id(source)
 
 
@@ -528,7 +590,7 @@ def _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache, raw=None
     """Sample rows of `source` for one storage chunk, ready for the accumulators: (fine [M, n], coarse [M, n] | None) as
     torch CUDA tensors (resident: served from / added to the HBM cache) or, when the chunk does not fit the cache budget
     and the tree is evaluated on the host, as NumPy arrays that go through the staging buffer of the C ABI."""
-    owner = getattr(plan.leaf, "_storage", plan.leaf) if plan is not None else source
+    owner = _owner_of(plan) if plan is not None else source
     ident = _cache_ident(source, plan)
     key = _chunk_key(ident, chunk_spec, n_collected)
     item = _device_cache.get(key) if use_cache else None
@@ -653,7 +715,7 @@ def _estimate_mean(quantity, group, variance):
     # estimate, the first one included, is one push per level and gives bit-identical sums.
     consolidate = use_cache and subsample_params is None
     ident = _cache_ident(source, plan)
-    owner = getattr(plan.leaf, "_storage", plan.leaf) if plan is not None else source
+    owner = _owner_of(plan) if plan is not None else source
 
     def push_pair(level_id, pair):
         nonlocal acc, n_comp
@@ -715,7 +777,7 @@ def _estimate_mean(quantity, group, variance):
     # resident): read ahead by a helper thread while this thread uploads and launches (_ChunkPrefetcher)
     to_read = []
     if plan is not None and _ChunkPrefetcher.enabled() and not hasattr(getattr(plan.leaf, "_storage", None), "device_row"):
-        have = _device_cache._items
+        have = _device_cache
         for cs in specs:
             key = _chunk_key(ident, cs, n_collected)
             resident = use_cache and (key in have or (("block", id(owner)) + key[1:]) in have

@@ -562,11 +562,90 @@ def g9_sampler_loop():
     with open(os.path.join(OUT, "G9_sampler_loop.json"), "w") as f:
         json.dump(dict(cases=cases), f)
 
+def g10_log_edges():
+    """Samples that sit ON the edges of a log-domain (Moments(log=True, safe_eval=True), moments.py:27-39,58-73): the
+    reference's keep / drop decision there depends on the last bit of np.log, which the device log() does not share.
+    The grid holds the doubles around both edges of the reference's keep interval (found here by bisection over the
+    reference's own ``transform``), the domain end points and their neighbours, non-positive values, inf and NaN; the
+    fixture records np.log(grid) as well, so a host whose NumPy log differs from this container's in one of these points
+    can be told apart from a product failure.  Also a two-level estimate_mean whose samples are drawn from that grid."""
+    import mlmc.moments as mm
+    import mlmc.quantity.quantity as q
+    import mlmc.quantity.quantity_estimate as qe
+
+    out = {}
+    cases = (("a", (0.05, 30.0), None), ("b", (1e-3, 7.5), (-0.5, 0.75)), ("c", (2.0, 2.0000001), None),
+             ("d", (1e-300, 1e300), None))
+    for tag, ldom, ref in cases:
+        fn = mm.Legendre(5, ldom, ref_domain=ref, log=True)
+
+        def kept(bits, fn=fn):
+            with np.errstate(all="ignore"):
+                return not np.isnan(fn.transform(np.array([bits], dtype=np.uint64).view(np.float64))[0])
+        top = 0x7ff0000000000000
+        # any kept point to split the two searches: the geometric middle of the domain
+        mid_bits = int(np.array([np.sqrt(ldom[0]) * np.sqrt(ldom[1])]).view(np.uint64)[0])
+        assert kept(mid_bits)
+        lo, hi = 1, mid_bits
+        while lo < hi:
+            m = (lo + hi) // 2
+            if kept(m):
+                hi = m
+            else:
+                lo = m + 1
+        first = lo
+        lo, hi = mid_bits, top - 1
+        while lo < hi:
+            m = (lo + hi + 1) // 2
+            if kept(m):
+                lo = m
+            else:
+                hi = m - 1
+        last = lo
+        edge_bits = []
+        for centre in (first, last, int(np.array([ldom[0]]).view(np.uint64)[0]), int(np.array([ldom[1]]).view(np.uint64)[0])):
+            edge_bits += [centre + k for k in range(-4, 5)]
+        grid = np.concatenate([np.array(edge_bits, dtype=np.uint64).view(np.float64),
+                               np.geomspace(ldom[0], ldom[1], 9), [0.0, -0.0, -1.0, 5e-324, 1e-320, np.inf, -np.inf, np.nan]])
+        out[tag + "_ldom"] = np.array(ldom)
+        out[tag + "_ref"] = np.array(ref if ref is not None else (-1.0, 1.0))
+        out[tag + "_grid"] = grid
+        out[tag + "_keep_interval"] = np.array([first, last], dtype=np.uint64).view(np.float64)
+        with np.errstate(all="ignore"):
+            out[tag + "_log"] = np.log(grid)
+            out[tag + "_legendre5"] = fn.eval_all(grid)
+            out[tag + "_monomial3"] = mm.Monomial(3, ldom, ref_domain=ref if ref is not None else None, log=True).eval_all(grid)
+            out[tag + "_legendre5_nosafe"] = mm.Legendre(5, ldom, ref_domain=ref, log=True, safe_eval=False).eval_all(grid)
+        # estimate_mean over two levels whose samples are drawn (seeded) from the grid: counts hinge on the edge decisions
+        rng = np.random.default_rng(77)
+        finite_pos = grid[np.isfinite(grid)]
+        N = [4001, 3001]
+        arrs = []
+        for l, n in enumerate(N):
+            a = np.empty((n, 2, 1))
+            a[:, 0, 0] = rng.choice(finite_pos, size=n)
+            a[:, 1, 0] = rng.choice(finite_pos, size=n) if l > 0 else 0.0
+            arrs.append(a)
+        spec = _scalar_spec()
+        st = make_storage(arrs, [[0.5], [0.1]], [1.0, 2.0], spec)
+        quantity = q.make_root_quantity(st, spec)['q'][1]['0'][0, 0]
+        with np.errstate(all="ignore"):
+            r = qe.estimate_mean(qe.moments(quantity, fn))
+        out[tag + "_est_fine0"] = arrs[0][:, 0, 0]
+        out[tag + "_est_fine1"] = arrs[1][:, 0, 0]
+        out[tag + "_est_coarse1"] = arrs[1][:, 1, 0]
+        out[tag + "_est_n"] = r.n_samples
+        out[tag + "_est_n_rm"] = r.n_rm_samples
+        out[tag + "_est_l_means"] = r.l_means
+        out[tag + "_est_l_vars"] = r.l_vars
+        print("G10", tag, "keep interval", out[tag + "_keep_interval"], "n", r.n_samples, "n_rm", r.n_rm_samples)
+    np.savez_compressed(os.path.join(OUT, "G10_log_edges.npz"), **out)
+
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     _install_shims()
-    which = sys.argv[1:] or ["g1", "g2", "g5", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g5", "g7", "g8", "g9", "g10"]
     if "g1" in which:
         g1_basis()
     if "g2" in which:
@@ -579,3 +658,5 @@ if __name__ == "__main__":
         g8_quantity_tree()
     if "g9" in which:
         g9_sampler_loop()
+    if "g10" in which:
+        g10_log_edges()

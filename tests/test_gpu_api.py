@@ -641,8 +641,10 @@ def test_compiled_programs_match_the_interpreter(hip, monkeypatch):
     root = make_root_quantity(st, _spec())
     dev = torch.device("cuda", 0)
     n_compiled = 0
+    monkeypatch.setenv("MLMC_EXPR_JIT_VERBOSE", "1")        # a hiprtc failure prints its log
     for name, q in expression_zoo(root).items():
         plan = lowering.lower(q)
+        n_jit = 0
         for chunk in st.chunks():
             stored = st.sample_pairs_level(chunk)
             pair = stored.shape[-1] == 2
@@ -650,18 +652,23 @@ def test_compiled_programs_match_the_interpreter(hip, monkeypatch):
             torch.cuda.synchronize()
             monkeypatch.setenv("MLMC_EXPR_JIT", "0")
             f0, c0, _ = plan.evaluate(rows, has_coarse=pair, n=stored.shape[1], sync=True)
+            assert plan.jit_state()[1] == n_jit, name                 # MLMC_EXPR_JIT=0: the interpreter ran
             f0, c0 = f0.cpu().numpy(), (None if c0 is None else c0.cpu().numpy())
             monkeypatch.setenv("MLMC_EXPR_JIT", "1")
             monkeypatch.setenv("MLMC_EXPR_JIT_AFTER", "0")
             f1, c1, _ = plan.evaluate(rows, has_coarse=pair, n=stored.shape[1], sync=True)
+            n_jit += 1
+            # the comparison below is compiled-vs-interpreter only if the compiled kernel really ran (a dlopen / hiprtc / module
+            # load failure falls back to the interpreter silently: state "failed")
+            assert plan.jit_state() == ("compiled", n_jit), (name, plan.jit_state())
             assert np.array_equal(f1.cpu().numpy(), f0, equal_nan=True), (name, chunk.level_id)
             if pair:
                 assert np.array_equal(c1.cpu().numpy(), c0, equal_nan=True), (name, chunk.level_id)
         n_compiled += 1
     assert n_compiled >= 20
-    # default policy: interpreter twice, compiled from the third evaluation on -- same rows every time, and the compiled
-    # kernel is not slower on a light tree over many samples (measured 5.7 against 5.1 TB/s on this tree, 6.0 against 4.9 on
-    # bench.py --config 6 whose average includes level-0 launches)
+    # interpreter twice (MLMC_EXPR_JIT=0: the compiled form of this program exists already, the cache is process-wide), then
+    # the compiled kernel -- same rows every time, and the compiled kernel is not slower on a light tree over many samples
+    # (measured 5.7 against 5.1 TB/s on this tree, 6.0 against 4.9 on bench.py --config 6 whose average includes level-0 launches)
     monkeypatch.delenv("MLMC_EXPR_JIT_AFTER")
     from mlmc_amd import _lib
     _lib.init(0, _lib.FLAG_TIMING)
@@ -673,9 +680,11 @@ def test_compiled_programs_match_the_interpreter(hip, monkeypatch):
     rows = [big[i % 2] for i in range(len(plan.in_rows))]
     times, first = [], None
     for it in range(8):
+        monkeypatch.setenv("MLMC_EXPR_JIT", "0" if it < 2 else "1")
         plan.kernel_time()
         f, c, _ = plan.evaluate(rows, has_coarse=True, n=n, sync=True)
         times.append(plan.kernel_time()[0])
+        assert plan.jit_state() == ("compiled", max(it - 1, 0)), (it, plan.jit_state())
         if first is None:
             first = (f.clone(), c.clone())
         else:
@@ -683,6 +692,38 @@ def test_compiled_programs_match_the_interpreter(hip, monkeypatch):
         del f, c
     assert min(times[3:]) < 1.02 * min(times[:2]), times
     _lib.init(0, 0)
+
+
+def test_compiled_program_with_more_than_64_stored_rows(hip, monkeypatch):
+    """A program declared over 65 stored rows whose LOADs all index rows < 64: mlmc_expr_eval passes the row pointers through
+    the device table (n_in_rows > 64), so the compiled kernel must read them from there too (round-2 advice: the generator
+    chose by the LOAD indices, read the zeroed by-value table and faulted from the third evaluation on).  Also: two handles
+    with identical instructions but row counts on either side of 64 must not share one compiled form."""
+    import ctypes as C
+    import torch
+    from mlmc_amd.quantity import lowering
+    lib = hip
+    monkeypatch.setenv("MLMC_EXPR_JIT", "1")
+    monkeypatch.setenv("MLMC_EXPR_JIT_AFTER", "0")
+    monkeypatch.setenv("MLMC_EXPR_JIT_VERBOSE", "1")
+    OP = lowering.OP
+    prog = [(OP["LOAD"], 0, 3, 0, 0.0), (OP["LOAD"], 1, 63, 0, 0.0), (OP["MUL"], 2, 0, 1, 0.0), (OP["STORE"], 0, 2, 0, 0.0)]
+    n = 5001
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    results = {}
+    for n_rows in (65, 64):
+        rows = [torch.randn(n, 2, dtype=torch.float64, device=dev, generator=g) for _ in range(n_rows)]
+        torch.cuda.synchronize()
+        plan = lowering.DevicePlan(None, list(range(n_rows)), 1, prog, 3, False)
+        for it in range(4):
+            f, c, _ = plan.evaluate(rows, has_coarse=True, n=n, sync=True)
+            assert plan.jit_state() == ("compiled", it + 1), plan.jit_state()
+            want_f = (rows[3][:, 0] * rows[63][:, 0]).cpu().numpy()
+            want_c = (rows[3][:, 1] * rows[63][:, 1]).cpu().numpy()
+            assert np.array_equal(f.cpu().numpy()[0], want_f) and np.array_equal(c.cpu().numpy()[0], want_c), (n_rows, it)
+        results[n_rows] = plan
 
 
 def test_device_tree_special_values(hip):

@@ -217,9 +217,13 @@ def test_bench_multi_rank_default_is_config3_sharded(hip):
     assert "configs[3]" in d["config"]["workload"] and d["config"]["estimate"] == "cov" and d["config"]["n_moments"] == 64
     assert d["config"]["samples_per_level_total"] == total and d["config"]["samples_per_level_per_gpu"] in (total // 2, total - total // 2)
     assert d["exchange"]["bytes_per_rank"] == 8 * (2 * 5 + 2 * 5 * 64 * 64) and d["exchange"]["allreduce_ms"] > 0
-    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1.2
-    # the symmetric tiles are computed once: fewer executed flops than the reference's count, a fraction that stays below 1
-    assert 0 < d["roofline"]["executed_mfma"]["frac"] < 1.0 and d["roofline"]["executed_mfma"]["frac"] < d["roofline"]["frac"]
+    # top level: executed matrix-core flops (symmetric tiles once) -- a physical fraction; the reference-form count rides beside it
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1.0
+    assert d["roofline"]["frac"] < d["roofline"]["reference_form"]["frac"]
+    n_loc = d["config"]["samples_per_level_per_gpu"]
+    assert d["roofline"]["executed_mfma_flops_per_step"] == 512 * (42 * 4 + 20) * n_loc
+    assert d["roofline"]["reference_form"]["alg_flops_reference_form"] == (6 * 64 * 64 + 14 * 64) * 4 * n_loc + (4 * 64 * 64 + 8 * 64) * n_loc
+    assert "traffic_from_profile" in d["roofline"] and (d["roofline"]["traffic"] is None or d["roofline"]["traffic_profile_matches_build"])
     rc = d["result_check"]
     assert rc["mean0"] == 1.0 and rc["var0"] == 0.0 and len(rc["n_estimated"]) == 5
     assert all(0 < r < 0.01 * total for r in rc["n_removed"])                          # both shards were counted

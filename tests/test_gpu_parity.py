@@ -62,9 +62,9 @@ def test_basis_eval_golden(hip, g1):
     for R in (1, 2, 5, 6, 33):
         got = Fourier(R, dom).eval_all(g1["grid"])
         ref = g1[f"fourier_R{R}_safe1"]
-        # reference quirk: Fourier column 0 is the constant 1 even for masked (NaN) inputs (moments.py:156);
-        # the device path marks the whole row NaN (the sample is dropped by mask_nan_samples either way)
-        assert _same_nan(got[:, 1:], ref[:, 1:]) and _vals_close(got[:, 1:], ref[:, 1:])
+        # reference quirk, kept: Fourier column 0 is the constant 1 even in the rows of masked (NaN) inputs (moments.py:156)
+        assert _same_nan(got, ref) and _vals_close(got, ref)
+        assert np.all(got[:, 0] == 1.0)
     assert np.array_equal(Legendre(4, (-1.0, 1.0))(np.array([0.0, 0.25, 0.5, 0.75, 1.0])), g1["kat_legendre"]) or \
         _vals_close(Legendre(4, (-1.0, 1.0))(np.array([0.0, 0.25, 0.5, 0.75, 1.0])), g1["kat_legendre"], 1e-15)
 

@@ -142,3 +142,41 @@ def test_concurrent_estimates_through_the_python_api(hip):
             # pass: equal to 1e-10, everything else bit for bit
             assert all(np.array_equal(x, y) for i, (x, y) in enumerate(zip(r, want)) if i != 4), key
             assert np.allclose(r[4], want[4], rtol=1e-10, atol=0), key
+
+
+def test_worker_threads_on_a_rank_bound_to_a_non_zero_device(tmp_path):
+    """HIP's current device is per host thread and defaults to 0: on a rank bound to device 1 a worker thread used to
+    allocate scratch and launch with device 0 current (round-2 advice).  Every entry point now re-binds the calling thread
+    (MLMC_API_GUARD -> bind_thread_to_device).  Needs two visible GPUs; a child process, because a process binds one device."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: a non-zero device index cannot be bound here")
+    code = r'''
+import threading, sys
+import numpy as np
+sys.path.insert(0, %r)
+from mlmc_amd import _lib, Legendre
+from mlmc_amd.engine import LevelAccumulator
+_lib.init(1)
+x = np.random.default_rng(0).standard_normal(200001)
+def job():
+    acc = LevelAccumulator(Legendre(24, (-3.7, 3.7)), 1, LevelAccumulator.COV)
+    acc.push(0, x, None)
+    return acc.finalize(reduce=False)
+want = job()
+out, err = [], []
+def run():
+    try:
+        out.append(job())
+    except BaseException as e:
+        err.append(e)
+ts = [threading.Thread(target=run) for _ in range(3)]
+[t.start() for t in ts]; [t.join(120) for t in ts]
+assert not err, err
+assert len(out) == 3 and all(all(np.array_equal(a, b) for a, b in zip(r, want)) for r in out)
+print("ok")
+''' % (str(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))),)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -4,10 +4,11 @@
 # itself (no env / shell wrappers: the profiler's preloaded library has initialised the GPU by then).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R
 rm -rf $O
 mkdir -p $O
+python3 -c "import bench; print(bench.csrc_sha())" > $O/csrc_sha.txt
 # the plain bench runs come first: the profiler passes (PMC in particular) can leave the GPU in another clock mode
 timeout -k 10 400 python3 bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 echo "bench default rc $?" > $O/progress.txt

@@ -54,6 +54,9 @@ for cfg in ("c2", "c3", "c6", "c5", "cd"):
                 e[c + "_avg_per_dispatch"] = sum(x) / len(x)
                 e["dispatches_" + kind] = len(x)
     if summary:
+        sha_file = os.path.join(src, "csrc_sha.txt")
+        if os.path.exists(sha_file):      # the build the counters were collected from (bench.csrc_sha on the GPU box)
+            summary["_meta"] = {"csrc_sha": open(sha_file).read().strip()}
         with open(os.path.join(dst, f"{rnd}_pmc_config{cfg[1]}.json"), "w") as out:
             json.dump(summary, out, indent=1, sort_keys=True)
     for name in (f"bench_{cfg}.json",):
