@@ -623,31 +623,42 @@ def tree_bench(args, cfg, world, rank, dev, dist):
 
 
 def pdf_solve_timing(fn, L, data, LevelAccumulator, level_stats):
-    """Estimate.construct_density's chain on this rank's HBM-resident samples (estimator.py:304-331): covariance pass ->
-    orthogonal moments (host LAPACK, R x R) -> moments pass in the orthogonal basis -> max-entropy Newton solve on the
-    device.  Only the means of the two estimates are used (as in the reference), so both run mean-only.  Reports the
-    solve alone and the whole chain, each for the first (cold) and the second call."""
+    """Estimate.construct_density's chain on this rank's HBM-resident samples (estimator.py:304-331): covariance mean ->
+    orthogonal moments (host LAPACK, R x R) -> means of the orthogonal moments -> max-entropy Newton solve on the device.
+    Only the means of the two estimates are used (as in the reference).  The estimates run the way
+    quantity_estimate._estimate_mean runs them for this basis.  Reports the solve alone and the whole chain, each for the
+    first (cold) and the second call."""
     from mlmc_amd.tool import simple_distribution as sd
+
+    from mlmc_amd import linearize
+    from mlmc_amd.quantity import quantity_estimate as qe
+    chunks = [(l, data[l][0], data[l][1]) for l in range(L)]
+    ext = qe._linearized_basis(fn)     # the product's own rule (quantity_estimate._estimate_mean): Legendre / monomial / Fourier
+    accs = {}
 
     def chain():
         t0 = time.perf_counter()
-        acc = LevelAccumulator(fn, L, LevelAccumulator.COV, mean_only=True)
-        for l in range(L):
-            acc.push(l, data[l][0], data[l][1])
-        n, _, s, _ = acc.finalize(reduce=False)      # rank-local: only rank 0 runs this chain, no collective
-        cov = np.sum(s / n[:, None], axis=0).reshape(fn.size, fn.size)
-        ortho, info = sd.construct_ortogonal_moments(fn, cov, tol=1e-4)
-        acc2 = LevelAccumulator(ortho, L, LevelAccumulator.MOMENTS, mean_only=True)
-        for l in range(L):
-            acc2.push(l, data[l][0], data[l][1])
-        n2, _, s2, _ = acc2.finalize(reduce=False)
-        means = np.sum(s2 / n2[:, None], axis=0)
+        if ext is not None:
+            # covariance mean from the level sums of 2 R - 1 moments (mlmc_amd/linearize.py): ONE pass of the mean-only
+            # moments kernel; the orthogonal-moments means are a linear map of the first R of the same sums
+            acc = accs.get("ext") or accs.setdefault("ext", LevelAccumulator(ext, L, LevelAccumulator.MOMENTS, mean_only=True))
+            n, _, s, _ = acc.estimate(chunks, reduce=False)      # rank-local: only rank 0 runs this chain, no collective
+            cov = np.sum(linearize.covariance_sums_from_moment_sums(fn, s) / n[:, None], axis=0).reshape(fn.size, fn.size)
+            ortho, info = sd.construct_ortogonal_moments(fn, cov, tol=1e-4)
+            means = ortho._base_matrix @ np.sum(s[:, :fn.size] / n[:, None], axis=0)
+        else:
+            acc = accs.get("cov") or accs.setdefault("cov", LevelAccumulator(fn, L, LevelAccumulator.COV, mean_only=True))
+            n, _, s, _ = acc.estimate(chunks, reduce=False)
+            cov = np.sum(s / n[:, None], axis=0).reshape(fn.size, fn.size)
+            ortho, info = sd.construct_ortogonal_moments(fn, cov, tol=1e-4)
+            acc2 = LevelAccumulator(ortho, L, LevelAccumulator.MOMENTS, mean_only=True)
+            n2, _, s2, _ = acc2.estimate(chunks, reduce=False)
+            means = np.sum(s2 / n2[:, None], axis=0)
+            acc2.close()
         t1 = time.perf_counter()
         distr = sd.SimpleDistribution(ortho, np.stack([means, np.ones_like(means)], axis=1), domain=fn.domain)
         res = distr.estimate_density_minimize(tol=1e-8)
         t2 = time.perf_counter()
-        acc.close()
-        acc2.close()
         return 1e3 * (t1 - t0), 1e3 * (t2 - t1), ortho, res
 
     gc.collect()
@@ -657,8 +668,13 @@ def pdf_solve_timing(fn, L, data, LevelAccumulator, level_stats):
         c2, s2, ortho, res = chain()
     finally:
         gc.enable()
+    for a in accs.values():
+        a.close()
     return {"solve_ms": round(s2, 3), "first_solve_ms": round(s1, 3), "estimate_chain_ms": round(c2, 3),
             "first_estimate_chain_ms": round(c1, 3), "n_moments_in": fn.size, "n_moments_orthogonal": int(ortho.size),
+            "estimate_chain": ("one mean-only moments pass of {} terms; covariance mean by product linearisation, orthogonal-moments "
+                               "means from the same sums".format(ext.size) if ext is not None else
+                               "matrix-core covariance pass (mean only) + moments pass over the orthogonal moments"),
             "nit": int(res.nit), "grad_norm": float(res.fun_norm), "success": bool(res.success)}
 
 

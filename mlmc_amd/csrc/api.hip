@@ -331,6 +331,10 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     // only the passes that exist solely for the second moments are skipped: the three-Gram covariance pass becomes one
     // Gram matrix, the diff-Gram pass of TransformedMoments disappears; plain moments keep their (free) sum of squares
     a->mean_only = mean_only && ((mode == MLMC_MODE_COV && b->out_size == 0) || (mode == MLMC_MODE_MOMENTS && b->out_size > 0));
+    // plain polynomial moments with 64 < R <= 128: the mean-only form of the term-split kernel covers them in ONE pass
+    // (moments.hip, k_moments_accum_split<..., SQ = false>); every other plain size keeps its free sums of squares
+    a->mean_only_plain = mean_only && mode == MLMC_MODE_MOMENTS && b->out_size == 0 &&
+                         (b->p.kind == MLMC_LEGENDRE || b->p.kind == MLMC_MONOMIAL) && b->p.size > 64 && b->p.size <= 128;
     a->n_comp = n_comp;
     a->R = b->p.size;
     a->Rout = b->out_size > 0 ? b->out_size : b->p.size;

@@ -17,6 +17,7 @@ from . import lowering
 from . import quantity as qmod
 from . import quantity_types as qt
 from .. import engine
+from .. import linearize
 
 
 def mask_nan_samples(chunk):
@@ -662,6 +663,38 @@ def _subsample_on_device(pair, params):
     return out_f, out_c
 
 
+def _linearized_basis(fn):
+    """The larger member of fn's family whose level SUMS give the level sums of fn's moment covariance (linearize.py):
+    Legendre / monomial / Fourier moments, `estimate_mean(covariance(q, fn), variance=False)`.  None: the covariance mean
+    stays on the matrix cores (splines, transformed moments, sizes the family does not reach; MLMC_HIP_LINEARIZE=0)."""
+    if os.environ.get("MLMC_HIP_LINEARIZE", "1") == "0":
+        return None
+    k_ext = linearize.extended_size(fn)
+    if k_ext is None or k_ext > 512:
+        return None
+    ext = fn.__dict__.get("_lin_ext")
+    if ext is None or ext.size != k_ext:
+        ext = fn.change_size(k_ext)
+        fn.__dict__["_lin_ext"] = ext          # one device handle and one pooled accumulator per moments object
+    return ext
+
+
+def _sums_from_linearized_memo(fn, key):
+    """Level sums of TransformedMoments(base, T) from the kept sums of a linearised covariance-mean estimate of `base` over the
+    same samples (same quantity rows, same level stamps, same cache generation): the transformed moments are linear in the
+    base moments, sum_n (T d_n) = T sum_n d_n, and the keep / drop decision is the base transform's.  This is the second
+    pass of Estimate.construct_density (estimator.py:304-331) without a second pass.  -> (n, n_rm, sums [L, n_comp * Rt]) | None"""
+    from ..moments import TransformedMoments
+    if not isinstance(fn, TransformedMoments) or key is None:
+        return None
+    memo = fn._base.__dict__.get("_lin_memo")
+    if memo is None or memo["key"] != key or fn._base_matrix.shape[1] != memo["R"]:
+        return None
+    L, n_comp, K, R = memo["sums"].shape[0], memo["n_comp"], memo["K"], memo["R"]
+    base = memo["sums"].reshape(L * n_comp, K)[:, :R]
+    return memo["n"].copy(), memo["n_rm"].copy(), (base @ fn._base_matrix.T).reshape(L, -1), n_comp
+
+
 def estimate_mean(quantity, group=None, variance=True):
     """MLMC mean estimator (reference: quantity_estimate.py:22-80).  Thread-safe: estimates of several host threads are
     serialised (one GPU stream, one sample cache, the memo of chunk evaluations shared by all quantities).
@@ -691,6 +724,15 @@ def _estimate_mean(quantity, group, variance):
         rows_per_comp = fn.size if mode == engine.LevelAccumulator.MOMENTS else fn.size * fn.size
     else:
         source, fn, mode, rows_per_comp = quantity, None, engine.LevelAccumulator.MOMENTS, 1
+    rows_out = rows_per_comp                                      # rows per component the caller sees
+    # Mean of the moment covariance without its variance (Estimate.construct_density): for Legendre / monomial / Fourier
+    # moments the R x R level sums are a fixed linear map of the level sums of ~2 R moments of the same family
+    # (linearize.py) -- one pass of the moments kernel instead of the matrix-core pass.
+    lin_fn = None
+    if mode == engine.LevelAccumulator.COV and not variance:
+        ext = _linearized_basis(fn)
+        if ext is not None:
+            lin_fn, fn, mode, rows_per_comp = fn, ext, engine.LevelAccumulator.MOMENTS, ext.size
 
     # bootstrap sub-sample of a quantity (Quantity.subsample): the chunks of the underlying quantity stay resident in HBM,
     # every estimate draws its random columns on the device (mlmc_subsample_gather)
@@ -724,7 +766,7 @@ def _estimate_mean(quantity, group, variance):
         if acc is None:
             n_comp = pair[0].shape[0]
             if pair[0].shape[-1] > 0:
-                assert n_comp * rows_per_comp == quantity_vec_size
+                assert n_comp * rows_out == quantity_vec_size
             acc = _acc_pool.take(fn, n_levels, mode, n_comp, mean_only=not variance)
         if pair[0].shape[-1] == 0:                               # empty chunk / every sample deselected
             return
@@ -764,6 +806,16 @@ def _estimate_mean(quantity, group, variance):
         for key in keys:
             _device_cache.drop(key)
         push_pair(level_id, merged)
+
+    memo_key = None
+    if n_collected is not None and subsample_params is None and group is None and not engine._dist_group_active(group):
+        memo_key = (ident, n_collected, _cache_generation)
+    if not variance and mode == engine.LevelAccumulator.MOMENTS and lin_fn is None and fn is not None:
+        short = _sums_from_linearized_memo(fn, memo_key)
+        if short is not None:
+            n_samples, n_rm_samples, sums, n_comp = short
+            return _finish_estimate(quantity, fn, n_levels, n_comp, rows_out, n_samples, n_rm_samples, sums,
+                                    np.full_like(sums, np.nan))
 
     level_done = set()
     if consolidate:
@@ -813,7 +865,17 @@ def _estimate_mean(quantity, group, variance):
     _acc_pool.give(fn, n_levels, mode, n_comp, acc, mean_only=not variance)
     if int(np.sum(n_samples)) == 0:
         raise Exception("All samples were masked")
+    if lin_fn is not None:
+        if memo_key is not None:
+            lin_fn.__dict__["_lin_memo"] = dict(key=memo_key, n=n_samples.copy(), n_rm=n_rm_samples.copy(), sums=sums.copy(),
+                                                n_comp=n_comp, K=fn.size, R=lin_fn.size)
+        sums = linearize.covariance_sums_from_moment_sums(lin_fn, sums, n_comp)
+        sums_sq = np.full_like(sums, np.nan)                       # mean only: the variances were not asked for
+        fn = lin_fn
+    return _finish_estimate(quantity, fn, n_levels, n_comp, rows_out, n_samples, n_rm_samples, sums, sums_sq)
 
+
+def _finish_estimate(quantity, fn, n_levels, n_comp, rows_per_comp, n_samples, n_rm_samples, sums, sums_sq):
     if fn is not None and not quantity._at_bottom and n_comp > 1:
         # device rows are (component, moment...); 'on the surface' wants (moment..., component)
         sums = sums.reshape(n_levels, n_comp, rows_per_comp).transpose(0, 2, 1).reshape(n_levels, -1)
