@@ -313,10 +313,10 @@ def exchange_block(fn, L, R, ctx, reps=50):
 def h2d_inclusive_block():
     """the first estimate over samples that still sit in a host storage, delivered the way SampleStorageHDF
     delivers them -- 300 chunks of 1e5 samples (3 levels x 1e7), every chunk a freshly allocated [n, 2, M] array
-    (Memory(copy_chunks=True) stands in for the HDF5 reads; h5py is not part of the image).  `stream` (the default feed): a
-    helper thread reads the chunks ahead while the main thread uploads and launches; `sync`: read, upload, launch one after
-    the other (MLMC_HIP_STREAM_UPLOAD=0); `pinned`: pinned staging ring + asynchronous DMA on a copy stream, kernels ordered
-    behind it by mlmc_wait_event (MLMC_HIP_STREAM_UPLOAD=pinned); `resident`: the next estimate, from HBM.  PCIe-inclusive
+    (Memory(copy_chunks=True) stands in for the HDF5 reads; h5py is not part of the image).  `stream` (the default feed,
+    quantity_estimate._LevelStreamer): helper threads read the chunks of a level into pinned staging blocks of 32 MB, one
+    asynchronous DMA per block, the level lands as ONE device tensor and the tree runs as one launch per level; `sync`: read,
+    upload, launch chunk by chunk (MLMC_HIP_STREAM_UPLOAD=0); `resident`: the next estimate, from HBM.  PCIe-inclusive
     figures are never the headline `value`."""
     from mlmc_amd import Legendre
     from mlmc_amd.estimator import Estimate, determine_level_parameters
@@ -340,10 +340,15 @@ def h2d_inclusive_block():
     saved = os.environ.get("MLMC_HIP_STREAM_UPLOAD")
     results = {}
     try:
-        for mode, flag in (("stream", "1"), ("sync", "0"), ("pinned", "pinned")):
+        for mode, flag, into in (("stream", "1", "1"), ("stream_arrays", "1", "0"), ("sync", "0", "0")):
+            # stream (the default feed): the storage writes every chunk straight into the pinned staging block
+            # (Memory.sample_records_into -- what an HDF5 storage does with Dataset.read_direct): one host copy per chunk;
+            # stream_arrays: every chunk arrives as a freshly allocated array (the reference's storage interface,
+            # sample_pairs_level) and is copied into the staging block: two host copies and freshly faulted pages per chunk
             os.environ["MLMC_HIP_STREAM_UPLOAD"] = flag
+            os.environ["MLMC_HIP_STREAM_READ_INTO"] = into
             times = []
-            for _ in range(1 if mode == "pinned" else 3):      # the pinned ring takes 0.5-1.5 s per pass on these hosts
+            for _ in range(3):
                 qe.device_cache_clear()
                 t0 = time.perf_counter()
                 results[mode] = est.estimate_moments()
@@ -355,9 +360,12 @@ def h2d_inclusive_block():
         for _ in range(5):
             warm = est.estimate_moments()
         out["resident_ms"] = round(1e3 * (time.perf_counter() - t0) / 5, 3)
-        out["same_result"] = bool(all(np.array_equal(a, b) for r in ("sync", "pinned") for a, b in zip(results["stream"], results[r]))
+        out["stream_threads"] = qe._LevelStreamer.n_threads()
+        out["stream_block_mb"] = qe._LevelStreamer.block_doubles() * 8 / 2 ** 20
+        out["same_result"] = bool(all(np.array_equal(a, b) for r in ("sync", "stream_arrays") for a, b in zip(results["stream"], results[r]))
                                   and all(np.array_equal(a, b) for a, b in zip(results["stream"], warm)))
     finally:
+        os.environ.pop("MLMC_HIP_STREAM_READ_INTO", None)
         if saved is None:
             os.environ.pop("MLMC_HIP_STREAM_UPLOAD", None)
         else:

@@ -204,81 +204,198 @@ def device_cache_drop_owner(storage):
         _block_meta.drop_owner(storage)
 
 
-class _StagingRing:
-    """Pinned staging for uploads of storage chunks, opt-in with MLMC_HIP_STREAM_UPLOAD=pinned.
+class _LevelStreamer:
+    """Streaming feed of a level that the storage delivers in many chunks (SampleStorageHDF reads one
+    `collected_values[chunk_slice]` per chunk and reopens the file every time, mlmc/tool/hdf5.py:353-376,
+    sample_storage_hdf.py:169-184): the chunks -- [n][2][M] record arrays, the layout of the reference's Memory storage and of
+    HDF5 `collected_values` -- are read by several helper threads straight into PINNED staging blocks of
+    MLMC_HIP_STREAM_BLOCK_MB (default 32), a block goes to HBM as ONE asynchronous DMA at link speed while the helpers fill
+    the next blocks, and the whole level lands in ONE device tensor in the storage's own layout: the quantity tree then runs
+    as one k_expr launch per level (strided LOAD: fine / coarse de-interleaving and the row gather on the device), every
+    other quantity of the analysis finds the level resident.  Reads (h5py, NumPy copies) and the copies into the staging
+    blocks release the GIL, so the helpers really run side by side; per chunk the main thread does nothing.
+    MLMC_HIP_STREAM_THREADS (default 4: more helpers contend for the page-fault lock and the GIL and lose) helpers; MLMC_HIP_STREAM_UPLOAD=0 switches the feed off (chunk by chunk, synchronously).
 
-    N pinned host buffers, one copy stream, one event per buffer.  A chunk is copied into the next free pinned buffer,
-    sent to HBM with an asynchronous DMA on the copy stream, and the library's stream is told to wait for that DMA
-    (mlmc_wait_event) -- the host does not wait for the transfer.  A buffer is reused when the DMA that read it has
-    completed.  Chunks above MLMC_HIP_STREAM_CHUNK_MB (default 32) skip the ring.
-    Measured on the MI355X boxes of this pool (tools/dev/gpu_stream_dev.py, 300 chunks of 1.6 MB): the extra host copy
-    into the pinned buffer runs at 4.5 GB/s and queueing one asynchronous copy + event costs 0.2-0.4 ms of host time --
-    as much as the whole synchronous pageable copy of the chunk (0.17-0.34 ms, the runtime stages it through its own
-    pinned buffers).  The ring is therefore NOT the default feed: the default overlaps the storage reads with the
-    uploads instead (_ChunkPrefetcher below); the ring remains for hosts where pinned staging pays."""
+    (Round 2 had a read-ahead thread that handed single chunks to the main thread -- one pageable copy, one k_expr launch and
+    ~100 us of Python per 1.6 MB chunk: 16 GB/s -- and an opt-in ring of chunk-sized pinned buffers whose per-chunk
+    asynchronous copy + event cost as much host time as the synchronous copy: 0.9 GB/s.  Both are gone.)"""
+    N_BUF = 3
 
-    def __init__(self, n_slots=3):
-        self._n = n_slots
-        self._pinned = [None] * n_slots
-        self._events = [None] * n_slots
-        self._next = 0
+    def __init__(self):
+        self._pinned = [None] * self.N_BUF
         self._stream = None
-        self.chunks = 0
+        self.blocks = 0            # staging blocks sent (tests)
+        self.levels = 0
 
     @staticmethod
     def enabled():
-        return os.environ.get("MLMC_HIP_STREAM_UPLOAD", "1") == "pinned"
+        return os.environ.get("MLMC_HIP_STREAM_UPLOAD", "1") != "0"
 
     @staticmethod
-    def limit_bytes():
-        return int(float(os.environ.get("MLMC_HIP_STREAM_CHUNK_MB", "32")) * 2 ** 20)
+    def block_doubles():
+        return max(int(float(os.environ.get("MLMC_HIP_STREAM_BLOCK_MB", "32")) * 2 ** 20) // 8, 1)
 
-    def upload(self, flat):
-        """flat: contiguous 1-D float64 host array -> device tensor of the same length.  Returns as soon as the DMA is
-        queued; everything the library launches afterwards is ordered behind it."""
+    @staticmethod
+    def n_threads():
+        return max(int(os.environ.get("MLMC_HIP_STREAM_THREADS", "4")), 1)
+
+    def _buffer(self, slot, doubles):
         import torch
-        from .. import _lib
+        buf = self._pinned[slot]
+        if buf is None or buf.numel() < doubles:
+            buf = self._pinned[slot] = torch.empty(doubles, dtype=torch.float64, pin_memory=True)
+        return buf
+
+    def stream(self, leaf, levels, n_rows_read, budget_bytes):
+        """levels: [(level id, [chunk specs of the level])].  Generator of (level id, block | None, first chunk | None) in the
+        order given: block = (flat device tensor, sample stride, side stride, n, width) once the level has landed; None when
+        the level does not qualify (unknown chunk sizes, not record arrays, too large) -- the caller then takes its chunks one
+        by one and must not read the first one again (it is handed back).  The levels are ONE pipeline: while the last block of
+        a level is on its way (and the caller queues the level's kernels) the helpers already fill the next level's blocks."""
+        import torch
+        plans = []                      # per qualifying level: dict(level, specs, sizes, sn, sw, m_total, width, raw0, out, blocks...)
+        early = []
+        for level_id, specs in levels:
+            sizes = []
+            for cs in specs:
+                sl = cs.chunk_slice
+                if sl is None or sl.start is None or sl.stop is None or sl.step not in (None, 1):
+                    sizes = None
+                    break
+                sizes.append(sl.stop - sl.start)
+            if sizes is None:
+                early.append((level_id, None, None))
+                continue
+            raw0 = leaf.samples(specs[0])
+            # (a one-row storage whose chunk already is an [n][2] row counts as a record array with M = 1 here)
+            layout = _block_layout(raw0, n_rows_read, True) if raw0.ndim == 3 and raw0.shape[1] == sizes[0] else None
+            n_total = sum(sizes)
+            if layout is None or n_total * layout[1] * 8 > budget_bytes or max(sizes) * layout[1] > 16 * self.block_doubles():
+                early.append((level_id, None, raw0))
+                continue
+            plans.append(dict(level=level_id, specs=specs, sizes=sizes, sn=layout[1], sw=layout[2], m_total=raw0.shape[0],
+                              width=raw0.shape[2], raw0=raw0, n_total=n_total))
+        for item in early:
+            yield item
+        if not plans:
+            return
         dev = torch.device("cuda", _lib_device())
-        n = flat.size
+        cap = max([self.block_doubles()] + [max(p["sizes"]) * p["sn"] for p in plans])
+        # global lists: tasks (one per chunk, in order) and staging blocks (consecutive chunks of ONE level)
+        tasks, blocks = [], []          # task: (plan index, chunk index, block index, offset in block); block: [plan index, length, tasks left, offset in level]
+        for pi, p in enumerate(plans):
+            p["out"] = torch.empty(p["n_total"] * p["sn"], dtype=torch.float64, device=dev)
+            cur_len, pos = 0, 0
+            blocks.append([pi, 0, 0, 0])
+            for ci, n_c in enumerate(p["sizes"]):
+                need = n_c * p["sn"]
+                if cur_len and cur_len + need > cap:
+                    pos += cur_len
+                    blocks.append([pi, 0, 0, pos])
+                    cur_len = 0
+                tasks.append((pi, ci, len(blocks) - 1, cur_len))
+                cur_len += need
+                blocks[-1][1] = cur_len
+                blocks[-1][2] += 1
+            p["last_block"] = len(blocks) - 1
+        views = [self._buffer(k, cap).numpy() for k in range(min(self.N_BUF, len(blocks)))]
+        # storages that can write a chunk's [n][2][M] records straight into a caller buffer (sample_storage.Memory
+        # .sample_records_into; an HDF5 storage: Dataset.read_direct) skip the intermediate array: one host copy, no fresh pages
+        into = getattr(getattr(leaf, "_storage", None), "sample_records_into", None)
+        if os.environ.get("MLMC_HIP_STREAM_READ_INTO", "1") == "0":
+            into = None
+        for p in plans:
+            p["into"] = into is not None and p["sn"] == 2 * p["m_total"] and (p["width"] == 1 or p["sw"] == p["m_total"])
+        cond = threading.Condition()
+        state = {"next": 0, "released": 0, "error": None}
+        ready = [threading.Event() for _ in blocks]
+
+        def worker():
+            while True:
+                with cond:
+                    if state["error"] is not None or state["next"] >= len(tasks):
+                        return
+                    pi, ci, b, off = tasks[state["next"]]
+                    state["next"] += 1
+                    while b >= state["released"] + self.N_BUF and state["error"] is None:   # its slot still holds an older block
+                        cond.wait(0.05)
+                    if state["error"] is not None:
+                        return
+                try:
+                    p = plans[pi]
+                    if p["into"] and ci > 0:                     # (chunk 0 was read as an array to learn the layout)
+                        n_c = p["sizes"][ci]
+                        into(p["specs"][ci], views[b % self.N_BUF][off:off + n_c * p["sn"]].reshape(n_c, 2, p["m_total"]))
+                        with cond:
+                            blocks[b][2] -= 1
+                            done = blocks[b][2] == 0
+                        if done:
+                            ready[b].set()
+                        continue
+                    raw = p["raw0"] if ci == 0 else leaf.samples(p["specs"][ci])
+                    lay = _block_layout(raw, n_rows_read, True) if raw.ndim == 3 else None
+                    if raw.shape != (p["m_total"], p["sizes"][ci], p["width"]) or lay is None or lay[1:] != (p["sn"], p["sw"]):
+                        raise ValueError("chunk {} of level {} does not continue the record layout of the level's first chunk"
+                                         .format(p["specs"][ci].chunk_id, p["specs"][ci].level_id))
+                    span = (p["sizes"][ci] - 1) * p["sn"] + (p["width"] - 1) * p["sw"] + p["m_total"]
+                    flat = np.lib.stride_tricks.as_strided(raw, shape=(span,), strides=(8,))
+                    np.copyto(views[b % self.N_BUF][off:off + span], flat)
+                except BaseException as e:                       # noqa: BLE001 - handed to the consumer
+                    with cond:
+                        state["error"] = e
+                        cond.notify_all()
+                    for ev in ready:
+                        ev.set()
+                    return
+                with cond:
+                    blocks[b][2] -= 1
+                    done = blocks[b][2] == 0
+                if done:
+                    ready[b].set()
+
+        threads = [threading.Thread(target=worker, name="mlmc-level-reader", daemon=True)
+                   for _ in range(min(self.n_threads(), len(tasks)))]
+        for t in threads:
+            t.start()
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=dev)
-        slot = self._next
-        self._next = (slot + 1) % self._n
-        if self._events[slot] is not None:
-            self._events[slot].synchronize()                     # the DMA that last read this buffer
-        buf = self._pinned[slot]
-        if buf is None or buf.numel() < n:
-            buf = self._pinned[slot] = torch.empty(max(n, 1 << 16), dtype=torch.float64, pin_memory=True)
-        buf[:n].copy_(torch.from_numpy(flat))
-        out = torch.empty(n, dtype=torch.float64, device=dev)
-        ev = self._events[slot]
-        if ev is None:
-            ev = self._events[slot] = torch.cuda.Event()
-        with torch.cuda.stream(self._stream):
-            out.copy_(buf[:n], non_blocking=True)
-            ev.record(self._stream)
-        _lib.check(_lib.lib().mlmc_wait_event(ev.cuda_event))
-        self.chunks += 1
-        return out
+        try:
+            for b, (pi, length, _, pos) in enumerate(blocks):
+                ready[b].wait()
+                if state["error"] is not None:
+                    raise state["error"]
+                p = plans[pi]
+                with torch.cuda.stream(self._stream):
+                    p["out"][pos:pos + length].copy_(self._pinned[b % self.N_BUF][:length], non_blocking=True)
+                self._stream.synchronize()                       # the helpers fill the other slots meanwhile
+                with cond:
+                    state["released"] = b + 1
+                    cond.notify_all()
+                self.blocks += 1
+                if b == p["last_block"]:
+                    self.levels += 1
+                    yield p["level"], (p["out"], p["sn"], p["sw"], p["n_total"], p["width"]), None
+        except BaseException:
+            with cond:
+                if state["error"] is None:
+                    state["error"] = RuntimeError("level stream aborted")
+                cond.notify_all()
+            raise
+        finally:
+            for t in threads:
+                t.join()
 
-    def drain(self):
-        for ev in self._events:
-            if ev is not None:
-                ev.synchronize()
 
-
-_staging = _StagingRing()
+_streamer = _LevelStreamer()
 
 
 def _upload(host_array, count=True):
-    """Host array (any shape, float64, C-contiguous) -> device tensor of the same shape: through the staging ring when the
-    chunk is small, as one synchronous pageable copy otherwise."""
+    """Host array (any shape, float64, C-contiguous) -> device tensor of the same shape, as one synchronous pageable copy (a
+    whole level in one chunk goes up at link speed that way; many-chunk levels take the _LevelStreamer)."""
     import torch
     a = np.ascontiguousarray(host_array, dtype=np.float64)
     if count:
         _device_cache.uploads += 1
-    if _StagingRing.enabled() and 0 < a.nbytes <= _StagingRing.limit_bytes():
-        return _staging.upload(a.reshape(-1)).view(a.shape)
     dev = torch.device("cuda", _lib_device())
     t = torch.from_numpy(a).to(dev)
     torch.cuda.current_stream(dev).synchronize()                 # the library reads it on its own stream
@@ -286,12 +403,10 @@ def _upload(host_array, count=True):
 
 
 class _ChunkPrefetcher:
-    """Streaming feed for storages that deliver a level in many chunks (SampleStorageHDF reads one
-    `collected_values[chunk_slice]` per chunk and reopens the file every time, mlmc/tool/hdf5.py:353-376): a helper thread
-    reads the chunks the estimate is going to miss, in order, up to `depth` ahead of the consumer (double buffering of host
-    chunks), while the main thread uploads the previous chunk and queues its kernels.  Storage reads (h5py, NumPy copies)
-    and the copy to the device both release the GIL, so the two legs really overlap; per chunk the feed costs
-    max(read, upload) instead of their sum.  MLMC_HIP_STREAM_UPLOAD=0 switches it off."""
+    """Read-ahead for the chunks the _LevelStreamer does not take (levels whose chunks are not record arrays -- their rows go
+    up one by one --, partly resident levels, chunk specs without slices): a helper thread reads the chunks the estimate is
+    going to miss, in order, up to `depth` ahead of the consumer, while the main thread uploads the previous chunk and queues
+    its kernels; per chunk the feed costs max(read, upload) instead of their sum.  MLMC_HIP_STREAM_UPLOAD=0 switches it off."""
 
     def __init__(self, leaf, specs, depth=2):
         import queue
@@ -304,7 +419,7 @@ class _ChunkPrefetcher:
 
     @staticmethod
     def enabled():
-        return os.environ.get("MLMC_HIP_STREAM_UPLOAD", "1") not in ("0", "pinned")
+        return os.environ.get("MLMC_HIP_STREAM_UPLOAD", "1") != "0"
 
     def _run(self):
         try:
@@ -405,7 +520,7 @@ def _stored_row_on_device(plan, chunk_spec, chunk_key, stored_row, use_cache, ra
     return t
 
 
-def _block_layout(raw, n_rows_read):
+def _block_layout(raw, n_rows_read, ready_rows_too=False):
     """Can the chunk view raw [M_stored, n, 2|1] go to the device as one flat copy of the storage's [n][sides][M] records?
     -> (span in doubles from the first to the last value, sample stride, side stride) or None (rows are uploaded one by
     one: they already are contiguous [n][2] / [n] rows, the tree reads less than 1/8 of a wide record, or the view is not
@@ -419,7 +534,7 @@ def _block_layout(raw, n_rows_read):
     if width == 1:
         sw = 0
     rows_are_ready = (sn == width and (width == 1 or sw == 1))   # raw[m] already is an [n][2] / [n] row
-    if rows_are_ready or (m_total > 1 and n_rows_read * 8 < m_total):
+    if (rows_are_ready and not ready_rows_too) or (m_total > 1 and n_rows_read * 8 < m_total):
         return None
     if sm != 1 or sn < m_total * width or (width == 2 and sw < m_total):
         return None                                              # not an [n][sides][M] record array
@@ -516,6 +631,54 @@ def _stored_block_on_device(plan, chunk_spec, chunk_key, use_cache, raw=None):
     else:
         t = item[0]
     return t, sn, sw, n, width
+
+
+def _level_blocks_on_device(plan, owner, levels, n_collected, use_cache, first_raw):
+    """The stored samples of whole levels as one device tensor each, in the storage's [n][2][M] layout, for levels the storage
+    hands out in several chunks: resident from an earlier estimate of any quantity over the same storage, or streamed now
+    (_LevelStreamer, all levels as one pipeline).  levels: [(level id, [chunk specs])].  Generator of
+    (level id, (flat tensor, sample stride, side stride, n, width)); levels that do not qualify are skipped (they are taken
+    chunk by chunk; a first chunk that was read on the way is left in `first_raw` for that path)."""
+    to_stream = []
+    for level_id, level_specs in levels:
+        stamp = None if n_collected is None else n_collected[level_id]
+        key = ("lvlblock", id(owner), level_id, stamp)
+        if use_cache:
+            item = _device_cache.get(key)
+            if item is not None and _block_meta.has(key, owner):
+                yield level_id, (item[0],) + _block_meta.get(key, owner)
+                continue
+            if _block_meta.has(key + ("no", len(plan.in_rows)), owner):
+                continue                                          # known: this level does not stream for a tree of that many rows
+        if len(level_specs) < 2 or not _LevelStreamer.enabled() or os.environ.get("MLMC_HIP_BLOCK_UPLOAD", "1") == "0":
+            continue
+        if use_cache:                                             # a level that is partly resident keeps its chunk-wise path
+            partly = False
+            for cs in level_specs:
+                ck = _chunk_key(None, cs, n_collected)[1:]
+                if (("block", id(owner)) + ck) in _device_cache or any((("row", id(owner)) + ck + (r,)) in _device_cache for r in plan.in_rows):
+                    partly = True
+                    break
+            if partly:
+                continue
+        to_stream.append((level_id, level_specs))
+    if not to_stream:
+        return
+    first_spec = {level_id: specs[0] for level_id, specs in to_stream}
+    for level_id, got, raw0 in _streamer.stream(plan.leaf, to_stream, len(plan.in_rows), _DeviceChunkCache.budget() // 4):
+        stamp = None if n_collected is None else n_collected[level_id]
+        key = ("lvlblock", id(owner), level_id, stamp)
+        if got is None:
+            if raw0 is not None:
+                first_raw[id(first_spec[level_id])] = raw0
+            if use_cache:
+                _block_meta.put(key + ("no", len(plan.in_rows)), owner, None)
+            continue
+        _device_cache.uploads += 1
+        if use_cache:
+            _device_cache.put_tensors(key, got[0], None, owner=owner)
+            _block_meta.put(key, owner, got[1:])
+        yield level_id, got
 
 
 def _evaluate_on_device(plan, chunk_spec, chunk_key, use_cache, raw=None):
@@ -818,23 +981,49 @@ def _estimate_mean(quantity, group, variance):
                                     np.full_like(sums, np.nan))
 
     level_done = set()
-    if consolidate:
+    if use_cache:
         for level_id in sorted({int(l) for l in level_ids}):
             item = _device_cache.get((ident, level_id, "level", n_collected[level_id]))
             if item is not None:
                 level_done.add(level_id)
-                push_pair(level_id, (item[0], item[1]))
+                pair = (item[0], item[1])
+                if subsample_params is not None and pair[0].shape[-1] > 0:   # the whole level is one resident chunk
+                    pair = _subsample_on_device(pair, subsample_params[level_id])
+                push_pair(level_id, pair)
     specs = [cs for cs in storage_q.chunks() if int(cs.level_id) not in level_done]
-    # chunks of a lowered tree that have to come from the host storage (neither their result rows nor their stored block are
-    # resident): read ahead by a helper thread while this thread uploads and launches (_ChunkPrefetcher)
+    host_storage = plan is not None and not hasattr(getattr(plan.leaf, "_storage", None), "device_row")
+    # Levels of a lowered tree that the storage hands out in several chunks of [n][2][M] records: the whole level becomes
+    # ONE device tensor in the storage's layout -- resident from an earlier estimate of any quantity over this storage, or
+    # streamed now through pinned staging blocks (_LevelStreamer) -- and the tree runs as ONE k_expr launch over it.
+    first_raw = {}
+    if host_storage:
+        by_level = collections.OrderedDict()
+        for cs in specs:
+            by_level.setdefault(int(cs.level_id), []).append(cs)
+        candidates = [(level_id, level_specs) for level_id, level_specs in by_level.items()
+                      if not (use_cache and any(_chunk_key(ident, cs, n_collected) in _device_cache for cs in level_specs))]
+        for level_id, blk in _level_blocks_on_device(plan, owner, candidates, n_collected, use_cache, first_raw):
+            t, sn, sw, n, width = blk
+            fine, coarse, _ = plan.evaluate([t[r:] for r in plan.in_rows], has_coarse=(width == 2), n=n, sample_stride=sn,
+                                            side_stride=max(sw, 1), sync=not use_cache)
+            if use_cache:
+                _device_cache.put_tensors((ident, level_id, "level", n_collected[level_id]), fine, coarse, owner=owner)
+            pair = (fine, coarse)
+            if subsample_params is not None and n > 0:
+                pair = _subsample_on_device(pair, subsample_params[level_id])
+            push_pair(level_id, pair)
+            level_done.add(level_id)
+        specs = [cs for cs in specs if int(cs.level_id) not in level_done]
+    # remaining chunks of a lowered tree that have to come from the host storage (neither their result rows nor their stored
+    # block are resident): read ahead by a helper thread while this thread uploads and launches (_ChunkPrefetcher)
     to_read = []
-    if plan is not None and _ChunkPrefetcher.enabled() and not hasattr(getattr(plan.leaf, "_storage", None), "device_row"):
+    if host_storage and _ChunkPrefetcher.enabled():
         have = _device_cache
         for cs in specs:
             key = _chunk_key(ident, cs, n_collected)
             resident = use_cache and (key in have or (("block", id(owner)) + key[1:]) in have
                                       or all((("row", id(owner)) + key[1:] + (r,)) in have for r in plan.in_rows))
-            if not resident:
+            if not resident and id(cs) not in first_raw:
                 to_read.append(cs)
     prefetch = _ChunkPrefetcher(plan.leaf, to_read) if len(to_read) > 1 else None
     waiting = {id(cs) for cs in to_read} if prefetch is not None else set()
@@ -845,7 +1034,7 @@ def _estimate_mean(quantity, group, variance):
             if level_id != current:
                 flush_level(current, pairs, keys)
                 current, pairs, keys = level_id, [], []
-            raw = prefetch.get(chunk_spec) if id(chunk_spec) in waiting else None
+            raw = prefetch.get(chunk_spec) if id(chunk_spec) in waiting else first_raw.pop(id(chunk_spec), None)
             pair = _chunk_for_device(source, plan, chunk_spec, n_collected, use_cache, raw)     # (fine [M, n], coarse | None)
             if pair is not None and subsample_params is not None and pair[0].shape[-1] > 0:
                 pair = _subsample_on_device(pair, subsample_params[level_id])

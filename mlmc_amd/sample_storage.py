@@ -195,6 +195,16 @@ class Memory(SampleStorage):
             chunk = chunk[:, :1, :]
         return chunk.transpose((2, 0, 1))
 
+    def sample_records_into(self, chunk_spec, out):
+        """Optional fast path of the storage interface (not part of the reference's SampleStorage): write the chunk's records
+        -- the storage layout [n][2][M], float64, what SampleStorageHDF keeps in `collected_values` (mlmc/tool/hdf5.py:14-46)
+        -- straight into `out`, a C-contiguous float64 array [n, 2, M] supplied by the caller.  The streaming feed
+        (quantity_estimate._LevelStreamer) hands in a window of a PINNED staging block, so a chunk costs one copy instead of
+        two and no freshly faulted pages; an HDF5-backed storage implements this with `Dataset.read_direct(out, np.s_[a:b])`."""
+        results = self._results[int(chunk_spec.level_id)]
+        chunk = results if chunk_spec.chunk_slice is None else results[chunk_spec.chunk_slice]
+        np.copyto(out, chunk.reshape(out.shape))
+
     def save_n_ops(self, n_ops):
         """n_ops: iterable of (level, (time, number of valid samples))"""
         for level, (time, n_samples) in n_ops:

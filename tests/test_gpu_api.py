@@ -470,7 +470,8 @@ def test_device_chunk_cache(hip):
     cache = qe._device_cache
     u0, h0 = cache.uploads, cache.hits
     m1, v1 = est.estimate_moments()
-    n_chunks = 3 + 2 + 1
+    n_chunks = 2 + 1            # uploads: the two levels that arrive in several chunks are streamed as ONE block each (3 and 2
+                                # chunks), the third level is one chunk
     assert cache.uploads - u0 == n_chunks and cache.hits == h0
     m2, v2 = est.estimate_moments()
     cov, _ = est.estimate_covariance()
@@ -493,9 +494,9 @@ def test_device_chunk_cache(hip):
 def test_streaming_feed_of_a_file_like_storage(hip, monkeypatch):
     """a storage that hands out every chunk as a fresh [n, 2, M] array (Memory(copy_chunks=True): the read
     pattern of SampleStorageHDF / LevelGroup.collected, mlmc/tool/hdf5.py:365-376 -- h5py itself is not part of the image,
-    the HDF5 byte format stays "parity unpinned") feeds the estimators (a) through the read-ahead thread (the default feed)
-    and (b) through the pinned staging ring (asynchronous DMA on a copy stream, the library's stream ordered behind it by
-    mlmc_wait_event).  Ragged chunk boundaries, more chunks than buffers, vector and scalar quantities, lowered trees and the
+    the HDF5 byte format stays "parity unpinned") feeds the estimators through the level streamer (helper threads fill pinned
+    staging blocks, one asynchronous DMA per block, one device tensor per level) or, where a level's chunks are not record
+    arrays, through the read-ahead thread.  Ragged chunk boundaries, more blocks than buffers, vector and scalar quantities, lowered trees and the
     host-evaluated path: every estimate equals, bit for bit, the estimate of the same samples from a one-chunk-per-level
     storage uploaded synchronously; a chunk is read from the storage once."""
     from mlmc_amd import Legendre
@@ -535,13 +536,17 @@ def test_streaming_feed_of_a_file_like_storage(hip, monkeypatch):
     monkeypatch.setenv("MLMC_HIP_STREAM_UPLOAD", "0")
     want = analyses(storage(None, False))                         # one chunk per level, synchronous uploads
     qe.device_cache_clear()
-    # (a) read-ahead thread: every chunk is read exactly once per estimate chain that misses it
+    # (a) the default feed: every chunk is read exactly once per estimate chain that misses it
     monkeypatch.setenv("MLMC_HIP_STREAM_UPLOAD", "1")
-    for chunk_size, records in ((3001, True), (977, True), (3001, False)):      # 14 + 9 + 3 and 41 + 26 + 10 chunks
+    # READ_INTO 1: the storage writes chunks straight into the pinned staging block (Memory.sample_records_into); 0: every chunk
+    # arrives as a fresh array through the reference's interface (sample_pairs_level)
+    for chunk_size, records, read_into in ((3001, True, "1"), (977, True, "0"), (3001, True, "0"), (3001, False, "1")):      # 14 + 9 + 3 and 41 + 26 + 10 chunks
+        monkeypatch.setenv("MLMC_HIP_STREAM_READ_INTO", read_into)
         st = storage(chunk_size, True, records)
         reads = []
-        inner = st.sample_pairs_level
+        inner, inner_into = st.sample_pairs_level, st.sample_records_into
         st.sample_pairs_level = lambda spec, inner=inner: reads.append((spec.level_id, spec.chunk_id)) or inner(spec)
+        st.sample_records_into = lambda spec, out, inner=inner_into: reads.append((spec.level_id, spec.chunk_id)) or inner(spec, out)
         got = analyses(st)
         n_chunks = sum(-(-n // chunk_size) for n in (40013, 25001, 9000))
         # record arrays: all four quantities share ONE upload of every chunk; component-major rows: a chunk is read again
@@ -550,6 +555,7 @@ def test_streaming_feed_of_a_file_like_storage(hip, monkeypatch):
         for g, w in zip(got, want):
             assert all(np.array_equal(a, b) for a, b in zip(g, w)), chunk_size
         qe.device_cache_clear()
+    monkeypatch.delenv("MLMC_HIP_STREAM_READ_INTO")
     # a storage that fails in the reader thread: the error surfaces in the caller
     st = storage(3001, True)
     inner = st.sample_pairs_level
@@ -559,34 +565,53 @@ def test_streaming_feed_of_a_file_like_storage(hip, monkeypatch):
             raise IOError("disk on fire")
         return inner(spec)
     st.sample_pairs_level = failing
+    st.sample_records_into = lambda spec, out: np.copyto(out, np.ascontiguousarray(failing(spec).transpose(1, 2, 0)))
     with pytest.raises(IOError, match="disk on fire"):
         analyses(st)
     qe.device_cache_clear()
-    # (b) pinned staging ring
-    monkeypatch.setenv("MLMC_HIP_STREAM_UPLOAD", "pinned")
-    for chunk_size in (3001, 977):
-        before = qe._staging.chunks
+    # (b) the block streamer itself: several staging blocks per level with ragged boundaries (a block limit of 0.2 MB against
+    # chunks of 96 / 31 KB), one helper thread and many, more blocks than pinned buffers; every level lands as one tensor
+    for block_mb, threads, chunk_size in (("0.2", "1", 3001), ("0.2", "5", 977), ("0.05", "3", 977)):
+        monkeypatch.setenv("MLMC_HIP_STREAM_BLOCK_MB", block_mb)
+        monkeypatch.setenv("MLMC_HIP_STREAM_THREADS", threads)
+        b0, l0 = qe._streamer.blocks, qe._streamer.levels
         got = analyses(storage(chunk_size, True))
-        assert qe._staging.chunks - before >= sum(-(-n // chunk_size) for n in (40013, 25001, 9000))
+        assert qe._streamer.levels - l0 == 3 and qe._streamer.blocks - b0 >= 8, (qe._streamer.blocks - b0, qe._streamer.levels - l0)
         for g, w in zip(got, want):
-            assert all(np.array_equal(a, b) for a, b in zip(g, w)), chunk_size
+            assert all(np.array_equal(a, b) for a, b in zip(g, w)), (block_mb, threads, chunk_size)
         qe.device_cache_clear()
-    # the host-evaluated path (tree evaluation switched off): chunks are split on the host and staged the same way
+    monkeypatch.delenv("MLMC_HIP_STREAM_BLOCK_MB")
+    monkeypatch.delenv("MLMC_HIP_STREAM_THREADS")
+    # a chunk that breaks the record layout of its level in the middle of the stream: the error surfaces, nothing hangs
+    st = storage(3001, True)
+    inner = st.sample_pairs_level
+
+    def ragged(spec):
+        raw = inner(spec)
+        return raw[:, :-1, :] if (spec.level_id, spec.chunk_id) == (0, 5) else raw
+    st.sample_pairs_level = ragged
+    monkeypatch.setenv("MLMC_HIP_STREAM_READ_INTO", "0")
+    with pytest.raises(ValueError, match="record layout"):
+        analyses(st)
+    monkeypatch.delenv("MLMC_HIP_STREAM_READ_INTO")
+    qe.device_cache_clear()
+    # the host-evaluated path (tree evaluation switched off): chunks are split on the host and go up one by one
     monkeypatch.setenv("MLMC_HIP_DEVICE_TREE", "0")
-    before = qe._staging.chunks
+    l0 = qe._streamer.levels
     got = analyses(storage(2500, True))
-    assert qe._staging.chunks > before
+    assert qe._streamer.levels == l0
     for g, w in zip(got, want):
         assert all(np.array_equal(a, b) for a, b in zip(g, w))
     qe.device_cache_clear()
-    # chunks above the staging limit take the one-copy path
     monkeypatch.setenv("MLMC_HIP_DEVICE_TREE", "1")
-    monkeypatch.setenv("MLMC_HIP_STREAM_CHUNK_MB", "0.001")
-    before = qe._staging.chunks
+    # the cache budget switched off: nothing stays resident, every chunk is read, uploaded and pushed on its own for every
+    # estimate (several pushes per level: the sums agree to rounding, not bit for bit)
+    monkeypatch.setenv("MLMC_HIP_DEVICE_CACHE_GB", "0")
     got = analyses(storage(3001, True))
-    assert qe._staging.chunks == before
     for g, w in zip(got, want):
-        assert all(np.array_equal(a, b) for a, b in zip(g, w))
+        assert all(np.allclose(a, b, rtol=1e-11, atol=1e-13) for a, b in zip(g, w))
+    assert len(qe._device_cache._items) == 0
+    monkeypatch.delenv("MLMC_HIP_DEVICE_CACHE_GB")
     qe.device_cache_clear()
 
 
@@ -879,8 +904,9 @@ def test_device_tree_block_upload_matches_row_upload(hip):
 
 
 def test_device_tree_block_upload_in_estimates(hip, monkeypatch):
-    """estimate_mean over trees that read many stored rows takes the block upload (one copy per chunk); results equal the
-    per-row path bit for bit and the number of uploads drops from rows x chunks to chunks."""
+    """estimate_mean over trees that read many stored rows takes the block upload (one device tensor per level: levels that
+    arrive in several chunks are streamed into it, a one-chunk level is one copy); results equal the per-row path bit for bit
+    and the number of uploads drops from rows x chunks to levels."""
     from mlmc_amd import Legendre
     from mlmc_amd.quantity import quantity_estimate as qe
     from mlmc_amd.quantity.quantity import make_root_quantity
@@ -897,7 +923,7 @@ def test_device_tree_block_upload_in_estimates(hip, monkeypatch):
         u0 = qe._device_cache.uploads
         res[mode] = (qe.estimate_mean(qe.moments(q, fn)), qe.estimate_mean(root))
         uploads[mode] = qe._device_cache.uploads - u0
-    assert uploads["1"] == n_chunks and uploads["0"] == 24 * n_chunks, (uploads, n_chunks)
+    assert uploads["1"] == 3 and uploads["0"] == 24 * n_chunks, (uploads, n_chunks)
     for a, b in zip(res["1"], res["0"]):
         assert a.n_samples.tolist() == b.n_samples.tolist()
         assert np.array_equal(a.l_means, b.l_means) and np.array_equal(a.l_vars, b.l_vars)
