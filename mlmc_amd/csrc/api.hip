@@ -321,8 +321,6 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     const bool mean_only = (mode & MLMC_MODE_MEAN_ONLY) != 0;
     mode &= ~MLMC_MODE_MEAN_ONLY;
     if (mode != MLMC_MODE_MOMENTS && mode != MLMC_MODE_COV) return fail("mlmc_accum_create: unknown mode");
-    if (mode == MLMC_MODE_COV && b->out_size > 64)
-        return fail("mlmc_accum_create: covariance of TransformedMoments supports at most 64 moments on the device path");
     mlmc_accum *a = new (std::nothrow) mlmc_accum();
     if (!a) return fail("out of memory");
     a->basis = b;
@@ -330,7 +328,9 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->mode = mode;
     // only the passes that exist solely for the second moments are skipped: the three-Gram covariance pass becomes one
     // Gram matrix, the diff-Gram pass of TransformedMoments disappears; plain moments keep their (free) sum of squares
-    a->mean_only = mean_only && ((mode == MLMC_MODE_COV && b->out_size == 0) || (mode == MLMC_MODE_MOMENTS && b->out_size > 0));
+    // covariance from materialised values: TransformedMoments, and plain bases beyond the 128 moments of the in-register kernels
+    a->cov_from_values = mode == MLMC_MODE_COV && (b->out_size > 0 || b->p.size > 128);
+    a->mean_only = mean_only && ((mode == MLMC_MODE_COV && !a->cov_from_values) || (mode == MLMC_MODE_MOMENTS && b->out_size > 0));
     // plain polynomial moments with 64 < R <= 128: the mean-only form of the term-split kernel covers them in ONE pass
     // (moments.hip, k_moments_accum_split<..., SQ = false>); every other plain size keeps its free sums of squares
     a->mean_only_plain = mean_only && mode == MLMC_MODE_MOMENTS && b->out_size == 0 &&
@@ -338,7 +338,7 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->n_comp = n_comp;
     a->R = b->p.size;
     a->Rout = b->out_size > 0 ? b->out_size : b->p.size;
-    a->RP = (((mode == MLMC_MODE_COV && b->out_size > 0 ? a->Rout : a->R) + 15) / 16) * 16;
+    a->RP = (((mode == MLMC_MODE_COV && b->out_size > 0 ? a->Rout : a->R) + 15) / 16) * 16;   // (plain bases: Rout == R)
     if (mode == MLMC_MODE_MOMENTS) {
         a->K = (int64_t)n_comp * a->Rout;
         a->int_width = 2 * (int64_t)a->R + (b->out_size > 0 ? (int64_t)a->RP * a->RP : 0);
@@ -455,11 +455,12 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             const bool defer = mem_kind == MLMC_DEVICE || a->n_comp > 1;
             rc = launch_moments_accum(a, level, m, f_m, c_m, d_mask, n, count, defer);
             if (!rc && a->basis->out_size > 0 && !a->mean_only) rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, false, 1);
-        } else if (a->basis->out_size > 0) {
-            // covariance of TransformedMoments: materialise the transformed moment values chunk by chunk
-            // (eval + matrix product), then the MFMA covariance kernel reads them back
+        } else if (a->cov_from_values) {
+            // covariance of TransformedMoments / of more than 128 moments: materialise the moment values chunk by chunk
+            // (eval [+ matrix product]), then the MFMA covariance kernel reads them back, one 64 x 64 output block per launch
             const int R1 = a->Rout;
-            const int64_t chunk = 1 << 18;
+            int64_t chunk = 1 << 18;
+            while (chunk > 4096 && chunk * R1 > ((int64_t)1 << 25)) chunk >>= 1;      // <= 256 MB of values per side
             const size_t need = sizeof(double) * (size_t)(n < chunk ? n : chunk) * R1;
             if (need > a->vals_cap) {
                 MLMC_HIP_CHECK(wait_stream(st));

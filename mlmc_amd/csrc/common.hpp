@@ -90,6 +90,7 @@ struct mlmc_accum {
     const mlmc_basis *basis = nullptr;
     int n_levels = 0, mode = 0, n_comp = 1;
     bool mean_only = false;       // MLMC_MODE_MEAN_ONLY: the second moments (sp) are not accumulated
+    bool cov_from_values = false; // COV: accumulated from materialised moment values (TransformedMoments; plain bases with R > 128)
     bool mean_only_plain = false; // ... requested for MOMENTS of a plain basis: honoured by the 65..128-term split kernel (sp = NaN)
     int R = 0;            // underlying family size
     int Rout = 0;         // rows per component seen by the caller (transform applied)

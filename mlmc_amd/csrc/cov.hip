@@ -133,11 +133,14 @@ __device__ __forceinline__ void cov_spline_store(const TermGen<MLMC_SPLINE> &g, 
 // VALS: `fine` / `coarse` hold already evaluated moment values [n][R] (row-major, NaN rows = masked samples) instead
 // of raw samples: the path for moment functions that are not evaluated in registers (TransformedMoments).
 template <int KIND, int T, bool PAIR, int MODE, int BI = 0, int BJ = 0, bool VALS = false>
-__global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 64)) ? 1 : 2) void k_cov_accum(BasisParams bp, 
+__global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 64 || VALS)) ? 1 : 2) void k_cov_accum(BasisParams bp, 
                                                       const double *__restrict__ fine,
                                                       const double *__restrict__ coarse,
                                                       const uint8_t *__restrict__ mask, int64_t n, int R,
-                                                      double *__restrict__ partials, int64_t *__restrict__ pcounts) {
+                                                      double *__restrict__ partials, int64_t *__restrict__ pcounts,
+                                                      int vals_ta, int vals_tb) {
+    // vals_ta / vals_tb (VALS only): first column of the row / column window inside the materialised value rows [n][R] -- run-time
+    // values, so ONE pair of instantiations (diagonal, off-diagonal) serves every 64 x 64 block of a covariance of any size
     constexpr int NT = 16 * T;                 // terms held in LDS
     // samples per batch: 128 for the small tiles evaluated from raw samples (all four waves run recurrences, the
     // barriers and the phase-1 latency are shared by twice the MFMA work), 64 otherwise
@@ -216,7 +219,9 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
                     keep = keep && (other != 0);
                 }
                 if (!is_coarse) { n_keep += (int)keep; n_rm += (int)(valid && !keep); }
-                for (int i = 0; i < NT; ++i) dst[i * STRIDE + samp] = (keep && i < R) ? row[i] : 0.0;
+                for (int i = 0; i < NT; ++i) dst[i * STRIDE + samp] = (keep && vals_ta + i < R) ? row[vals_ta + i] : 0.0;
+                if (WIDE)
+                    for (int i = 0; i < NT; ++i) dst_b[i * STRIDE + samp] = (keep && vals_tb + i < R) ? row[vals_tb + i] : 0.0;
             }
         } else if (evaluator) {
             const int64_t idx = batch * BATCH + samp;
@@ -775,9 +780,9 @@ static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, int ncomp,
         return 0;
     }
     if (pair)
-        hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE, BI, BJ>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
+        hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE, BI, BJ>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts, 0, 0);
     else
-        hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE, BI, BJ>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
+        hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE, BI, BJ>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts, 0, 0);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -796,47 +801,63 @@ static int launch_cov_kind(const BasisParams &bp, int T, int bi, int bj, bool pa
     return fail("covariance: at most 128 moments");
 }
 
-// Covariance accumulation from materialised moment values [n][R1] (TransformedMoments): the generic kernel with VALS.
+// Covariance accumulation from materialised moment values [n][R1]: the generic kernel with VALS.  The path of moment
+// functions that are not evaluated in registers -- TransformedMoments (any number of rows) and plain bases beyond the 128
+// moments the compile-time term windows cover (up to the 512 the library accepts): the reference has no size limit
+// (quantity_estimate.py:122-156).  More than 64 moments: 64 x 64 output blocks, the window offsets are kernel arguments.
 int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_vf, const double *d_vc, const uint8_t *d_mask,
                            int64_t n, bool count) {
     if (n == 0) return 0;
-    const int R = a->Rout;
-    if (R > 64) return fail("covariance of TransformedMoments supports at most 64 moments on the device path");
+    const int R = a->cov_from_values && a->basis->out_size == 0 ? a->R : a->Rout;
     hipStream_t st = rt().stream;
     const int T = (R <= 16) ? 1 : (R <= 32 ? 2 : 4);
     const int NT = 16 * T, NSL = 4 / T;
     const bool pair = d_vc != nullptr;
+    const int NB = (R + 63) / 64;
     const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
     const size_t width = (size_t)3 * NT * NT;
-    int blocks = rt().n_cu * 2;
-    if (n_batches < blocks) blocks = (int)n_batches;
-    const int n_slices = T <= 2 ? 4 : NSL;             // partial rows per workgroup (k_cov_accum: SLICED)
-    if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * n_slices * width)) return rc;
-    if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
-    int64_t *pc = count ? a->d_pcounts : nullptr;
     const BasisParams &bp = a->basis->p;
-#define MLMC_COV_VALS(TT)                                                                                                       \
+    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
+    for (int bi = 0; bi < NB; ++bi)
+        for (int bj = 0; bj < NB; ++bj) {
+            if (!pair && bj < bi) continue;   // level 0: symmetric matrices, block (bj, bi) is mirrored by the reduction
+            const bool wide = bi != bj;
+            int blocks = rt().n_cu * (wide ? 1 : 2);          // two term windows: 135 KB of LDS, one workgroup per CU
+            if (n_batches < blocks) blocks = (int)n_batches;
+            const int n_slices = T <= 2 ? 4 : NSL;             // partial rows per workgroup (k_cov_accum: SLICED)
+            if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * n_slices * width)) return rc;
+            if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
+            const bool do_count = count && bi == 0 && bj == 0;
+            int64_t *pc = do_count ? a->d_pcounts : nullptr;
+            if (int rc = timing_begin(a)) return rc;
+#define MLMC_COV_VALS(TT, BJJ)                                                                                                  \
     do {                                                                                                                        \
         if (pair)                                                                                                               \
-            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, true, 0, 0, 0, true>), dim3(blocks), dim3(256), 0, st, bp,           \
-                               d_vf, d_vc, d_mask, n, R, a->d_partials, pc);                                                    \
+            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, true, 0, 0, BJJ, true>), dim3(blocks), dim3(256), 0, st, bp,         \
+                               d_vf, d_vc, d_mask, n, R, a->d_partials, pc, 64 * bi, 64 * bj);                                  \
         else                                                                                                                    \
-            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, false, 0, 0, 0, true>), dim3(blocks), dim3(256), 0, st, bp,          \
-                               d_vf, d_vc, d_mask, n, R, a->d_partials, pc);                                                    \
+            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, false, 0, 0, BJJ, true>), dim3(blocks), dim3(256), 0, st, bp,        \
+                               d_vf, d_vc, d_mask, n, R, a->d_partials, pc, 64 * bi, 64 * bj);                                  \
     } while (0)
-    if (T == 1) MLMC_COV_VALS(1);
-    else if (T == 2) MLMC_COV_VALS(2);
-    else MLMC_COV_VALS(4);
+            if (T == 1) MLMC_COV_VALS(1, 0);
+            else if (T == 2) MLMC_COV_VALS(2, 0);
+            else if (!wide) MLMC_COV_VALS(4, 0);
+            else MLMC_COV_VALS(4, 1);
 #undef MLMC_COV_VALS
-    MLMC_HIP_CHECK(hipGetLastError());
-    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
-    hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, 3, a->RP, 0,
-                       0, totals, (int64_t)0, 0);
-    MLMC_HIP_CHECK(hipGetLastError());
-    if (count) {
-        hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
-        MLMC_HIP_CHECK(hipGetLastError());
-    }
+            MLMC_HIP_CHECK(hipGetLastError());
+            if (int rc = timing_end(a)) return rc;
+            a->launches += 1;
+            a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
+            // the generic kernel's tile lists: no symmetric savings inside a block except the SLICED (T <= 2) upper tiles
+            a->mfma_flops += (int64_t)512 * n * (T <= 2 ? (pair ? 2 * T * T + T * (T + 1) / 2 : T * (T + 1)) : (pair ? 3 : 2) * 16);
+            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, 3,
+                               a->RP, 64 * bi, 64 * bj, totals, (int64_t)0, (!pair && wide) ? 1 : 0);
+            MLMC_HIP_CHECK(hipGetLastError());
+            if (do_count) {
+                hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
+                MLMC_HIP_CHECK(hipGetLastError());
+            }
+        }
     return 0;
 }
 
@@ -857,7 +878,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     const bool diff_gram_only = gram_mode == 1;   // gram_mode: 0 = G0, G1, G2; 1 = D^T D into the moments' Gram slot; 2 = G0 only
     if (n == 0) return 0;
     const int R = a->R;
-    if (R > 128) return fail("covariance accumulation supports at most 128 moments on the device path");
+    if (R > 128) return fail("covariance accumulation in registers covers 128 moments; larger bases go through launch_cov_from_values");
     hipStream_t st = rt().stream;
     const int T = (R <= 16) ? 1 : (R <= 32 ? 2 : 4);
     const int NT = 16 * T, NSL = 4 / T;
@@ -944,7 +965,7 @@ __global__ void k_cov_finalize(const double *__restrict__ totals, const double *
 
 int launch_cov_finalize(mlmc_accum *a) {
     const int n_lc = a->n_levels * a->n_comp;
-    const bool vals = a->basis->out_size > 0;          // covariance of TransformedMoments: accumulated from true values
+    const bool vals = a->cov_from_values;              // TransformedMoments / more than 128 moments: accumulated from true values
     const int R = vals ? a->Rout : a->R;
     hipLaunchKernelGGL(k_cov_finalize, dim3((R * R + 255) / 256, n_lc), dim3(256), 0, rt().stream, a->d_totals,
                        vals ? (const double *)nullptr : a->basis->d_scale, R,

@@ -342,7 +342,7 @@ def test_fourier_and_transformed_accumulate(hip):
     _check_against(n, n_rm, s, sp, ref)
     # TransformedMoments: variance through the accumulated second moments T G T^T
     rng = np.random.default_rng(3)
-    for R0, R1 in ((9, 6), (33, 33), (64, 40)):
+    for R0, R1 in ((9, 6), (33, 33), (64, 40), (80, 70), (40, 100), (150, 130)):      # more than 64 rows: 64 x 64 output blocks
         mat = rng.normal(size=(R1, R0)) / np.sqrt(R0)
         mat[0] = 0
         mat[0, 0] = 1
@@ -454,9 +454,11 @@ def test_device_resident_inputs_and_large_property(hip):
         assert close(s3[l], so, rms_l, 1e-10) and close(sp3[l], spo, None, 1e-10)
 
 
-@pytest.mark.parametrize("R", [65, 80, 128])
+@pytest.mark.parametrize("R", [65, 80, 128, 129, 200, 320])
 def test_covariance_more_than_64_moments(hip, R):
-    """R > 64: the covariance is assembled from 64 x 64 term-window blocks (two LDS windows off the diagonal)."""
+    """R > 64: the covariance is assembled from 64 x 64 blocks -- up to 128 moments from term windows evaluated in registers
+    (two LDS windows off the diagonal), beyond that (the reference has no size limit, quantity_estimate.py:122-156; the library
+    accepts 512 Legendre moments) from moment values materialised chunk by chunk, the window offsets run-time arguments."""
     from mlmc_amd import Legendre, TransformedMoments
     from mlmc_amd.engine import LevelAccumulator
     dom = (-3.7, 3.7)
@@ -749,7 +751,7 @@ def test_covariance_of_transformed_moments(hip):
     dom = (-3.7, 3.7)
     levels = level_arrays([3000, 2001, 700], [0.5, 0.07, 0.01], 1, 9)
     rng = np.random.default_rng(8)
-    for R0, R1 in ((9, 6), (33, 33), (64, 40)):
+    for R0, R1 in ((9, 6), (33, 33), (64, 40), (80, 70), (40, 100), (150, 130)):      # more than 64 rows: 64 x 64 output blocks
         mat = rng.normal(size=(R1, R0)) / np.sqrt(R0)
         mat[0] = 0
         mat[0, 0] = 1
