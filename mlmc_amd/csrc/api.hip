@@ -454,7 +454,33 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             // together when the push ends (below)
             const bool defer = mem_kind == MLMC_DEVICE || a->n_comp > 1;
             rc = launch_moments_accum(a, level, m, f_m, c_m, d_mask, n, count, defer);
-            if (!rc && a->basis->out_size > 0 && !a->mean_only) rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, false, 1);
+            if (!rc && a->basis->out_size > 0 && !a->mean_only) {
+                if (a->R <= 128) {
+                    rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, false, 1);
+                } else {
+                    // difference Gram of more than 128 underlying moments: from materialised (scaled) values, chunk by chunk
+                    int64_t chunk = 1 << 18;
+                    while (chunk > 4096 && chunk * a->R > ((int64_t)1 << 25)) chunk >>= 1;
+                    const size_t need = sizeof(double) * (size_t)(n < chunk ? n : chunk) * a->R;
+                    if (need > a->vals_cap) {
+                        MLMC_HIP_CHECK(wait_stream(st));
+                        if (a->d_vals_f) (void)hipFree(a->d_vals_f);
+                        if (a->d_vals_c) (void)hipFree(a->d_vals_c);
+                        a->d_vals_f = a->d_vals_c = nullptr;
+                        a->vals_cap = 0;
+                        MLMC_HIP_CHECK(hipMalloc(&a->d_vals_f, need));
+                        MLMC_HIP_CHECK(hipMalloc(&a->d_vals_c, need));
+                        a->vals_cap = need;
+                    }
+                    for (int64_t off = 0; off < n && !rc; off += chunk) {
+                        const int64_t m_n = (n - off < chunk) ? n - off : chunk;
+                        rc = launch_eval_scaled_base(a->basis, f_m + off, m_n, a->d_vals_f);
+                        if (!rc && c_m) rc = launch_eval_scaled_base(a->basis, c_m + off, m_n, a->d_vals_c);
+                        if (!rc) rc = launch_cov_from_values(a, level, m, a->d_vals_f, c_m ? a->d_vals_c : nullptr,
+                                                             d_mask ? d_mask + off : nullptr, m_n, false, 1);
+                    }
+                }
+            }
         } else if (a->cov_from_values) {
             // covariance of TransformedMoments / of more than 128 moments: materialise the moment values chunk by chunk
             // (eval [+ matrix product]), then the MFMA covariance kernel reads them back, one 64 x 64 output block per launch

@@ -130,6 +130,7 @@ struct mlmc_accum {
 namespace mlmc {
 // moments.hip
 int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, double *d_out, double *scratch = nullptr);
+int launch_eval_scaled_base(const mlmc_basis *b, const double *d_x, int64_t n, double *d_out);
 int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64_t n, uint8_t *d_mask, int64_t *d_counts_level);
 int launch_moments_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
                          int64_t n, bool count, bool defer);
@@ -140,7 +141,7 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
                      int64_t n, bool count, int gram_mode, int ncomp = 1);
 int launch_cov_finalize(mlmc_accum *a);
 int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_vf, const double *d_vc, const uint8_t *d_mask,
-                           int64_t n, bool count);
+                           int64_t n, bool count, int gram_mode = 0);
 int ensure(void **p, size_t *cap, size_t bytes);
 int timing_begin(mlmc_accum *a);
 int timing_end(mlmc_accum *a);

@@ -805,53 +805,65 @@ static int launch_cov_kind(const BasisParams &bp, int T, int bi, int bj, bool pa
 // functions that are not evaluated in registers -- TransformedMoments (any number of rows) and plain bases beyond the 128
 // moments the compile-time term windows cover (up to the 512 the library accepts): the reference has no size limit
 // (quantity_estimate.py:122-156).  More than 64 moments: 64 x 64 output blocks, the window offsets are kernel arguments.
+// gram_mode 1: the difference Gram matrix D^T D of the UNDERLYING moments (values [n][a->R] in the accumulators' scaling) into
+// the Gram slot of a MOMENTS accumulator of TransformedMoments (variance = diag(T G T^T)): symmetric, upper blocks only.
 int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_vf, const double *d_vc, const uint8_t *d_mask,
-                           int64_t n, bool count) {
+                           int64_t n, bool count, int gram_mode) {
     if (n == 0) return 0;
-    const int R = a->cov_from_values && a->basis->out_size == 0 ? a->R : a->Rout;
+    const bool diff_gram = gram_mode == 1;
+    const int R = diff_gram ? a->R : a->Rout;
     hipStream_t st = rt().stream;
     const int T = (R <= 16) ? 1 : (R <= 32 ? 2 : 4);
     const int NT = 16 * T, NSL = 4 / T;
     const bool pair = d_vc != nullptr;
     const int NB = (R + 63) / 64;
     const int64_t n_batches = (n + COV_BATCH - 1) / COV_BATCH;
-    const size_t width = (size_t)3 * NT * NT;
+    const int NG = diff_gram ? 1 : 3;
+    const size_t width = (size_t)NG * NT * NT;
     const BasisParams &bp = a->basis->p;
-    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
+    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram ? 2 * (int64_t)R : 0);
+    const bool symmetric = !pair || diff_gram;
     for (int bi = 0; bi < NB; ++bi)
         for (int bj = 0; bj < NB; ++bj) {
-            if (!pair && bj < bi) continue;   // level 0: symmetric matrices, block (bj, bi) is mirrored by the reduction
+            if (symmetric && bj < bi) continue;   // symmetric matrices (level 0; D^T D): block (bj, bi) is mirrored by the reduction
             const bool wide = bi != bj;
             int blocks = rt().n_cu * (wide ? 1 : 2);          // two term windows: 135 KB of LDS, one workgroup per CU
             if (n_batches < blocks) blocks = (int)n_batches;
             const int n_slices = T <= 2 ? 4 : NSL;             // partial rows per workgroup (k_cov_accum: SLICED)
             if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * n_slices * width)) return rc;
             if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
-            const bool do_count = count && bi == 0 && bj == 0;
+            const bool do_count = count && bi == 0 && bj == 0 && !diff_gram;
             int64_t *pc = do_count ? a->d_pcounts : nullptr;
             if (int rc = timing_begin(a)) return rc;
-#define MLMC_COV_VALS(TT, BJJ)                                                                                                  \
+#define MLMC_COV_VALS1(TT, BJJ, MODE)                                                                                           \
     do {                                                                                                                        \
         if (pair)                                                                                                               \
-            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, true, 0, 0, BJJ, true>), dim3(blocks), dim3(256), 0, st, bp,         \
+            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, true, MODE, 0, BJJ, true>), dim3(blocks), dim3(256), 0, st, bp,      \
                                d_vf, d_vc, d_mask, n, R, a->d_partials, pc, 64 * bi, 64 * bj);                                  \
         else                                                                                                                    \
-            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, false, 0, 0, BJJ, true>), dim3(blocks), dim3(256), 0, st, bp,        \
+            hipLaunchKernelGGL((k_cov_accum<MLMC_IDENTITY, TT, false, MODE, 0, BJJ, true>), dim3(blocks), dim3(256), 0, st, bp,     \
                                d_vf, d_vc, d_mask, n, R, a->d_partials, pc, 64 * bi, 64 * bj);                                  \
+    } while (0)
+#define MLMC_COV_VALS(TT, BJJ)                                                                                                  \
+    do {                                                                                                                        \
+        if (diff_gram) MLMC_COV_VALS1(TT, BJJ, 1); else MLMC_COV_VALS1(TT, BJJ, 0);                                             \
     } while (0)
             if (T == 1) MLMC_COV_VALS(1, 0);
             else if (T == 2) MLMC_COV_VALS(2, 0);
             else if (!wide) MLMC_COV_VALS(4, 0);
             else MLMC_COV_VALS(4, 1);
 #undef MLMC_COV_VALS
+#undef MLMC_COV_VALS1
             MLMC_HIP_CHECK(hipGetLastError());
             if (int rc = timing_end(a)) return rc;
-            a->launches += 1;
-            a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
-            // the generic kernel's tile lists: no symmetric savings inside a block except the SLICED (T <= 2) upper tiles
-            a->mfma_flops += (int64_t)512 * n * (T <= 2 ? (pair ? 2 * T * T + T * (T + 1) / 2 : T * (T + 1)) : (pair ? 3 : 2) * 16);
-            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, 3,
-                               a->RP, 64 * bi, 64 * bj, totals, (int64_t)0, (!pair && wide) ? 1 : 0);
+            if (!diff_gram) {
+                a->launches += 1;
+                a->alg_bytes += (int64_t)n * (pair ? 16 : 8);
+                // the generic kernel's tile lists: no symmetric savings inside a block except the SLICED (T <= 2) upper tiles
+                a->mfma_flops += (int64_t)512 * n * (T <= 2 ? (pair ? 2 * T * T + T * (T + 1) / 2 : T * (T + 1)) : (pair ? 3 : 2) * 16);
+            }
+            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, NG,
+                               a->RP, 64 * bi, 64 * bj, totals, (int64_t)0, (symmetric && wide) ? 1 : 0);
             MLMC_HIP_CHECK(hipGetLastError());
             if (do_count) {
                 hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);

@@ -33,7 +33,7 @@ __global__ void k_eval(BasisParams bp, const double *__restrict__ scale_c,
     const double nan = __builtin_nan("");
     for (int r = 0; r < size; ++r) {
         double q = g.next(r);
-        if (KIND == MLMC_LEGENDRE) q *= scale_c[r];
+        if (KIND == MLMC_LEGENDRE && scale_c) q *= scale_c[r];     // scale_c == nullptr: the scaled q_i the accumulators sum
         out[i * size + r] = keep ? q : nan;
     }
 }
@@ -48,6 +48,26 @@ __global__ void k_apply_matrix(const double *__restrict__ phi, const double *__r
     double acc = 0.0;
     for (int r = 0; r < R0; ++r) acc = __builtin_fma(phi[i * R0 + r], T[(int64_t)j * R0 + r], acc);
     out[idx] = acc;
+}
+
+// Values of the UNDERLYING family in the accumulators' scaling (Legendre: q_i = P_i / c_i), [n][b->p.size]: the input of the
+// difference Gram matrix of TransformedMoments over more than 128 underlying moments (launch_cov_from_values, gram_mode 1).
+int launch_eval_scaled_base(const mlmc_basis *b, const double *d_x, int64_t n, double *d_out) {
+    if (n == 0) return 0;
+    hipStream_t st = rt().stream;
+    const int threads = 256;
+    const int64_t blocks = (n + threads - 1) / threads;
+    const BasisParams &bp = b->p;
+    const double *no_scale = nullptr;
+    switch (bp.kind) {
+        case MLMC_LEGENDRE: hipLaunchKernelGGL(k_eval<MLMC_LEGENDRE>, dim3(blocks), dim3(threads), 0, st, bp, no_scale, d_x, n, bp.size, d_out); break;
+        case MLMC_MONOMIAL: hipLaunchKernelGGL(k_eval<MLMC_MONOMIAL>, dim3(blocks), dim3(threads), 0, st, bp, no_scale, d_x, n, bp.size, d_out); break;
+        case MLMC_FOURIER: hipLaunchKernelGGL(k_eval<MLMC_FOURIER>, dim3(blocks), dim3(threads), 0, st, bp, no_scale, d_x, n, bp.size, d_out); break;
+        case MLMC_SPLINE: hipLaunchKernelGGL(k_eval<MLMC_SPLINE>, dim3(blocks), dim3(threads), 0, st, bp, no_scale, d_x, n, bp.size, d_out); break;
+        default: return fail("unknown basis kind");
+    }
+    MLMC_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_eval(const mlmc_basis *b, const double *d_x, int64_t n, int size, double *d_out, double *scratch) {
@@ -443,66 +463,83 @@ __device__ __forceinline__ void split_import(TermGen<KIND> &g, const double *__r
     g.c1 = g.s1 = 0.0;
 }
 
-template <int KIND, bool PAIR, bool PLAIN, int HT, int TT, bool SQ>
+// NS = samples per head lane and trip (one workgroup barrier per trip).  Hand-over image per buffer: [NS * (PAIR ? 2 : 1)]
+// recurrences x 3 words x SPLIT_LANES lanes; the kernel sizes it for pairs.
+#ifndef MLMC_SPLIT_NS
+#define MLMC_SPLIT_NS 2
+#endif
+template <int KIND, bool PAIR, bool PLAIN, int HT, int TT, bool SQ, int NS>
 __device__ __forceinline__ void split_head(const BasisParams &bp, const double *__restrict__ fine, const double *__restrict__ coarse,
                                            const uint8_t *__restrict__ mask, int64_t n, int bid, int nb, int n_trips,
                                            double *__restrict__ hand, double (&s)[split_max(HT, TT)], double (&sp)[split_max(HT, TT)],
                                            int &n_keep, int &n_rm) {
     const int64_t T = (int64_t)nb * SPLIT_LANES;
     const int l128 = threadIdx.x & (SPLIT_LANES - 1);
-    int64_t i0 = (int64_t)bid * SPLIT_LANES + l128, i1 = i0 + T;
-    double f0 = 0, f1 = 0, c0 = 0, c1 = 0;
-    uint8_t m0 = 1, m1 = 1;
-    if (i0 < n) { f0 = fine[i0]; if (PAIR) c0 = coarse[i0]; if (!PLAIN && mask) m0 = mask[i0]; }
-    if (i1 < n) { f1 = fine[i1]; if (PAIR) c1 = coarse[i1]; if (!PLAIN && mask) m1 = mask[i1]; }
+    int64_t idx[NS];
+    double f[NS], c[NS];
+    uint8_t m[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        idx[q] = (int64_t)bid * SPLIT_LANES + l128 + q * T;
+        // loads are unconditional on a clamped index (n > 0 here; `valid` decides what counts): a load under a lane
+        // mask is merged into the old value after an s_waitcnt right behind it, and the prefetch would hide nothing
+        const int64_t j = idx[q] < n ? idx[q] : n - 1;
+        f[q] = fine[j];
+        c[q] = PAIR ? coarse[j] : 0.0;
+        m[q] = (!PLAIN && mask) ? mask[j] : (uint8_t)1;
+    }
     MLMC_SPLIT_PRIO_INIT
     for (int k = 0; k < n_trips; ++k) {
         MLMC_SPLIT_PRIO_TRIP
-        const bool v0 = i0 < n, v1 = i1 < n;
-        const double xf0 = f0, xf1 = f1, xc0 = c0, xc1 = c1;
-        const uint8_t mm0 = m0, mm1 = m1;
-        const int64_t j0 = i0 + 2 * T, j1 = i1 + 2 * T;      // next trip's loads first
-        if (j0 < n) { f0 = fine[j0]; if (PAIR) c0 = coarse[j0]; if (!PLAIN && mask) m0 = mask[j0]; }
-        if (j1 < n) { f1 = fine[j1]; if (PAIR) c1 = coarse[j1]; if (!PLAIN && mask) m1 = mask[j1]; }
-        bool kf0, kf1, kc0 = true, kc1 = true;
-        const double tf0 = PLAIN ? transform_plain(bp, xf0, kf0) : transform_value(bp, xf0, kf0);
-        const double tf1 = PLAIN ? transform_plain(bp, xf1, kf1) : transform_value(bp, xf1, kf1);
-        double tc0 = 0, tc1 = 0;
-        if (PAIR) {
-            tc0 = PLAIN ? transform_plain(bp, xc0, kc0) : transform_value(bp, xc0, kc0);
-            tc1 = PLAIN ? transform_plain(bp, xc1, kc1) : transform_value(bp, xc1, kc1);
+        bool valid[NS];
+        double xf[NS], xc[NS];
+        uint8_t mm[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            valid[q] = idx[q] < n;
+            xf[q] = f[q]; xc[q] = c[q]; mm[q] = m[q];
+            idx[q] += (int64_t)NS * T;                            // next trip's loads first (clamped, unconditional: see above)
+            const int64_t j = idx[q] < n ? idx[q] : n - 1;
+            f[q] = fine[j];
+            if (PAIR) c[q] = coarse[j];
+            if (!PLAIN && mask) m[q] = mask[j];
         }
-        const bool k0 = v0 && kf0 && kc0 && (PLAIN || mm0 != 0);
-        const bool k1 = v1 && kf1 && kc1 && (PLAIN || mm1 != 0);
-        n_keep += (int)k0 + (int)k1;
-        n_rm += (int)(v0 && !k0) + (int)(v1 && !k1);
-        const double w0 = k0 ? 1.0 : 0.0, w1 = k1 ? 1.0 : 0.0;
-        TermGen<KIND> gf0, gf1, gc0, gc1;
-        gf0.init(k0 ? tf0 : 0.0, w0, bp);
-        gf1.init(k1 ? tf1 : 0.0, w1, bp);
-        if (PAIR) { gc0.init(k0 ? tc0 : 0.0, w0, bp); gc1.init(k1 ? tc1 : 0.0, w1, bp); }
+        TermGen<KIND> gf[NS], gc[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            bool kf, kc = true;
+            const double tf = PLAIN ? transform_plain(bp, xf[q], kf) : transform_value(bp, xf[q], kf);
+            double tc = 0;
+            if (PAIR) tc = PLAIN ? transform_plain(bp, xc[q], kc) : transform_value(bp, xc[q], kc);
+            const bool keep = valid[q] && kf && kc && (PLAIN || mm[q] != 0);
+            n_keep += (int)keep;
+            n_rm += (int)(valid[q] && !keep);
+            const double w = keep ? 1.0 : 0.0;
+            gf[q].init(keep ? tf : 0.0, w, bp);
+            if (PAIR) gc[q].init(keep ? tc : 0.0, w, bp);
+        }
 #pragma unroll
         for (int i = 0; i < HT; ++i) {
-            double d0 = gf0.next(i);
-            double d1 = gf1.next(i);
-            if (PAIR) { d0 -= gc0.next(i); d1 -= gc1.next(i); }
-            s[i] += d0;
-            if (SQ) sp[i] = __builtin_fma(d0, d0, sp[i]);
-            s[i] += d1;
-            if (SQ) sp[i] = __builtin_fma(d1, d1, sp[i]);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                double d = gf[q].next(i);
+                if (PAIR) d -= gc[q].next(i);
+                s[i] += d;
+                if (SQ) sp[i] = __builtin_fma(d, d, sp[i]);
+            }
         }
-        double *__restrict__ slot = hand + (size_t)(k & 1) * (12 * SPLIT_LANES) + l128;
-        split_export<KIND>(gf0, slot);
-        split_export<KIND>(gf1, slot + 3 * SPLIT_LANES);
-        if (PAIR) { split_export<KIND>(gc0, slot + 6 * SPLIT_LANES); split_export<KIND>(gc1, slot + 9 * SPLIT_LANES); }
+        double *__restrict__ slot = hand + (size_t)(k & 1) * (6 * NS * SPLIT_LANES) + l128;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            split_export<KIND>(gf[q], slot + (3 * q) * SPLIT_LANES);
+            if (PAIR) split_export<KIND>(gc[q], slot + (3 * (NS + q)) * SPLIT_LANES);
+        }
         __syncthreads();
-        i0 = j0;
-        i1 = j1;
     }
     __syncthreads();      // the tail's last trip
 }
 
-template <int KIND, bool PAIR, int HT, int TT, bool SQ>
+template <int KIND, bool PAIR, int HT, int TT, bool SQ, int NS>
 __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, const double *__restrict__ hand,
                                            double (&s)[split_max(HT, TT)], double (&sp)[split_max(HT, TT)]) {
     const int l128 = threadIdx.x & (SPLIT_LANES - 1);
@@ -510,20 +547,22 @@ __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, c
     MLMC_SPLIT_PRIO_INIT
     for (int k = 0; k < n_trips; ++k) {
         MLMC_SPLIT_PRIO_TRIP
-        const double *__restrict__ slot = hand + (size_t)(k & 1) * (12 * SPLIT_LANES) + l128;
-        TermGen<KIND> gf0, gf1, gc0, gc1;
-        split_import<KIND>(gf0, slot);
-        split_import<KIND>(gf1, slot + 3 * SPLIT_LANES);
-        if (PAIR) { split_import<KIND>(gc0, slot + 6 * SPLIT_LANES); split_import<KIND>(gc1, slot + 9 * SPLIT_LANES); }
+        const double *__restrict__ slot = hand + (size_t)(k & 1) * (6 * NS * SPLIT_LANES) + l128;
+        TermGen<KIND> gf[NS], gc[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            split_import<KIND>(gf[q], slot + (3 * q) * SPLIT_LANES);
+            if (PAIR) split_import<KIND>(gc[q], slot + (3 * (NS + q)) * SPLIT_LANES);
+        }
 #pragma unroll
         for (int i = 0; i < TT; ++i) {
-            double d0 = gf0.next(HT + i);
-            double d1 = gf1.next(HT + i);
-            if (PAIR) { d0 -= gc0.next(HT + i); d1 -= gc1.next(HT + i); }
-            s[i] += d0;
-            if (SQ) sp[i] = __builtin_fma(d0, d0, sp[i]);
-            s[i] += d1;
-            if (SQ) sp[i] = __builtin_fma(d1, d1, sp[i]);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                double d = gf[q].next(HT + i);
+                if (PAIR) d -= gc[q].next(HT + i);
+                s[i] += d;
+                if (SQ) sp[i] = __builtin_fma(d, d, sp[i]);
+            }
         }
         __syncthreads();
     }
@@ -535,11 +574,11 @@ __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, c
 // registers, so ONE pass covers up to 128 terms (62 + 66) at 6 instead of 7 instructions per term and pair: the pass behind
 // `estimate_mean(covariance(q, fn), variance=False)` for Legendre / monomial moments, whose R x R level means follow
 // from the level sums of 2 R - 1 moments (mlmc_amd/linearize.py; Estimate.construct_density, estimator.py:304-331).
-template <int KIND, bool PLAIN, int HT, int TT, int WPS, bool SQ = true>
+template <int KIND, bool PLAIN, int HT, int TT, int WPS, bool SQ = true, int NS = MLMC_SPLIT_NS>
 __global__ __launch_bounds__(ACC_THREADS, WPS) void k_moments_accum_split(BasisParams bp, SegTable tab,
                                                                         double *__restrict__ partials,
                                                                         int64_t *__restrict__ pcounts) {
-    __shared__ double hand[2 * 12 * SPLIT_LANES];      // [buffer][recurrence (f0, f1, c0, c1) x (x, Q_31, Q_30)][lane]
+    __shared__ double hand[2 * 6 * NS * SPLIT_LANES];  // [buffer][recurrence (NS fine, NS coarse) x (x, Q_k-1, Q_k-2)][lane]
     constexpr int MAXT = split_max(HT, TT), NTOT = HT + TT;
     __shared__ double wsum[4][2 * MAXT];
     __shared__ int ldc[2][2];
@@ -551,7 +590,7 @@ __global__ __launch_bounds__(ACC_THREADS, WPS) void k_moments_accum_split(BasisP
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // trips of this workgroup (uniform): lane 0 of trip k starts at sample bid * 128 + k * 2 T
-    const int64_t T2 = 2 * (int64_t)sg.nblocks * SPLIT_LANES;
+    const int64_t T2 = NS * (int64_t)sg.nblocks * SPLIT_LANES;
     const int64_t first = (int64_t)bid * SPLIT_LANES;
     const int n_trips = first < sg.n ? (int)((sg.n - first + T2 - 1) / T2) : 0;
 
@@ -560,11 +599,11 @@ __global__ __launch_bounds__(ACC_THREADS, WPS) void k_moments_accum_split(BasisP
     for (int i = 0; i < MAXT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
     int n_keep = 0, n_rm = 0;
     if (wave < 2) {
-        if (sg.coarse) split_head<KIND, true, PLAIN, HT, TT, SQ>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
-        else split_head<KIND, false, PLAIN, HT, TT, SQ>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
+        if (sg.coarse) split_head<KIND, true, PLAIN, HT, TT, SQ, NS>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
+        else split_head<KIND, false, PLAIN, HT, TT, SQ, NS>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
     } else {
-        if (sg.coarse) split_tail<KIND, true, HT, TT, SQ>(bp, n_trips, hand, s, sp);
-        else split_tail<KIND, false, HT, TT, SQ>(bp, n_trips, hand, s, sp);
+        if (sg.coarse) split_tail<KIND, true, HT, TT, SQ, NS>(bp, n_trips, hand, s, sp);
+        else split_tail<KIND, false, HT, TT, SQ, NS>(bp, n_trips, hand, s, sp);
     }
     // ---- block partial: butterfly sums inside every wave (fixed order), then head pair / tail pair added in fixed order ----
 #pragma unroll
@@ -920,7 +959,7 @@ int flush_moments(mlmc_accum *a) {
             const PendingSeg &p = a->pending[k];
             // floor: the whole grid must be resident at once (one block over the limit would run as a second round)
             int nb = (int)((double)resident * ((double)p.n * (p.coarse ? W_PAIR : W_SINGLE)) / wsum);
-            const int64_t per_trip = 2 * (split ? SPLIT_LANES : ACC_THREADS);      // samples a workgroup takes per trip
+            const int64_t per_trip = split ? (int64_t)MLMC_SPLIT_NS * SPLIT_LANES : 2 * ACC_THREADS;      // samples a workgroup takes per trip
             const int64_t want = (p.n + per_trip - 1) / per_trip;
             if (nb > want) nb = (int)want;
             if (nb < 1) nb = 1;

@@ -85,6 +85,33 @@ class Distribution:
         result.fun_norm = jac_norm
         return result
 
+    def estimate_density(self, tol=None):
+        """Root of the gradient from the uniform initial guess at the full size, no size continuation ("faster, but worse
+        stability", reference: distribution.py:159-181 -- `scipy.optimize.root(fun=gradient, jac=Hessian, tol=tol)`).
+        As written the reference method cannot run: it calls `_initialize_params(tol)`, which binds `tol` to the `size`
+        parameter and fails its own `assert tol is not None` (:216-223), and nothing in the reference calls it.  Built here
+        to its evident intent: initial guess of `_initialize_params(approx_size, tol)`, no stabilisation term (there is no
+        previous stage), the decay penalties of the functional as in every other solve; the Newton iteration of
+        `mlmc_maxent_solve` finds the root.  -> OptimizeResult with x, fun (the gradient), success, nit, fun_norm; the
+        normalisation is not touched, as in the reference.  The result is pinned to the reference through
+        `estimate_density_minimize(reg_param=0)`, whose solution is the root of the same gradient."""
+        assert tol is not None
+        self._reg_param = 0.0
+        self._initialize_params(self.approx_size, tol)
+        self._last_solved_multipliers = None
+        self._stab_penalty = 0.0
+        self._moment_means = self.moment_means[:self.approx_size]
+        self._moment_errs = self.moment_errs[:self.approx_size]
+        lam, grad, hess, info = self._solve_stage(tol=tol, max_it=200)
+        self.multipliers = lam
+        result = OptimizeResult()
+        result.x = lam.copy()
+        result.fun = grad
+        result.nit = info.nit
+        result.fun_norm = float(np.linalg.norm(grad))
+        result.success = bool(info.success) or result.fun_norm < tol
+        return result
+
     def _solve_stage(self, tol, max_it):
         if max_it == 0:
             # evaluate only: one Newton set-up with an unreachable iteration budget returns gradient info at the start

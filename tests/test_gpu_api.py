@@ -333,6 +333,32 @@ def test_old_distribution_solver(hip):
             assert abs(l2 - float(g6[key + "_L2"])) <= 1e-5 * float(g6[key + "_L2"]) + 1e-7, (key, l2, float(g6[key + "_L2"]))
 
 
+def test_distribution_estimate_density_root_variant(hip):
+    """Distribution.estimate_density (reference distribution.py:159-181, `scipy.optimize.root` on the gradient).  The
+    reference method raises as written (`_initialize_params(tol)` binds tol to `size` and trips `assert tol is not None`,
+    :216-223; recorded by tests/test_host_logic.py from the reference's source) -- so there is no reference output to pin
+    against directly.  Built to its intent, it must find the root of the same gradient as the staged minimiser with
+    reg_param = 0, which IS pinned to the reference's results (G6 *_old_*): multipliers before the normalisation fix, density."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.tool import distribution as dd
+    g6 = np.load(os.path.join(GOLDEN, "G6_maxent.npz"))
+    for name in ("norm12", "norm110", "lognorm"):
+        for R in (5, 11):
+            key = f"{name}_old_R{R}"
+            dom = tuple(g6[key + "_domain"])
+            d1 = dd.Distribution(Legendre(R, dom), g6[key + "_moment_data"].copy(), domain=dom, force_decay=(True, True))
+            r1 = d1.estimate_density(tol=1e-8)
+            assert r1.success and r1.fun_norm < 1e-8 and r1.fun.shape == (R,) and r1.nit >= 1, (key, r1.fun_norm)
+            d2 = dd.Distribution(Legendre(R, dom), g6[key + "_moment_data"].copy(), domain=dom, force_decay=(True, True))
+            r2 = d2.estimate_density_minimize(tol=1e-8, reg_param=0.0)
+            assert np.max(np.abs(r1.x - r2.x)) <= 1e-6 * np.max(np.abs(r2.x)), key
+            xg, ref = g6[key + "_xgrid"], g6[key + "_density"]
+            # the reference's density carries its normalisation fix (multipliers / zeroth moment), which is 1 to quadrature accuracy
+            assert np.max(np.abs(d1.density(xg) - ref)) <= 2e-5 * np.max(ref), key
+    with pytest.raises(AssertionError):
+        dd.Distribution(Legendre(5, (0.0, 1.0)), np.ones((5, 2))).estimate_density()      # tol is required (:223)
+
+
 def _golden_pdf(name, dom):
     """The truncated, renormalised densities of oracle/gen_golden.py::g5_g6 (test/test_distribution.py: CutDistribution)."""
     import scipy.stats as stats

@@ -292,3 +292,39 @@ def test_device_chunk_cache_accounting(monkeypatch):
     assert list(cache._items) == ["k4"] and cache._bytes == 100 * 8
     cache.clear()
     assert cache._bytes == 0 and not cache._items and cache.get("k4") is None
+
+
+def test_level_stats_beyond_two_to_the_53_equal_the_reference_formula():
+    """n = 1e8 samples per level (BASELINE configs[3]): s = sum of P_0 differences = n at level 0, and s * s = 1e16 passes
+    2^53, so var_0 = (sp - s^2 / n) / (n - 1) is no longer exactly 0 for every n -- in the reference's own formula
+    (quantity_estimate.py:72-77) just as here.  engine.level_stats must equal the oracle's restatement of that formula bit
+    for bit, whatever it gives; `vars[0] == 0` exactly is guaranteed only while n^2 < 2^53, i.e. n < 9.49e7 per level."""
+    from mlmc_amd.engine import level_stats
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(3)
+    for n0 in (94_906_265, 94_906_267, 100_000_000, 99_987_653, 500_000_000):
+        n = np.array([n0, n0 - 12345, 7])
+        s = np.stack([n.astype(np.float64), rng.normal(size=3) * np.sqrt(n)], axis=1)       # column 0: phi_0 = 1 at level 0 ...
+        s[1:, 0] = 0.0                                                                       # ... and differences 0 above
+        sp = np.stack([n.astype(np.float64), np.abs(rng.normal(size=3)) * n], axis=1)
+        sp[1:, 0] = 0.0
+        l_means, l_vars = level_stats(n, s, sp)
+        ref_means, ref_vars = onp.level_stats(s, sp, n)
+        assert np.array_equal(l_means, ref_means) and np.array_equal(l_vars, ref_vars)
+        assert l_means[0, 0] == 1.0
+        if n0 <= 94_906_265:                      # floor(sqrt(2^53)): n * n is still exact
+            assert l_vars[0, 0] == 0.0
+
+
+def test_reference_estimate_density_root_variant_cannot_run_as_written():
+    """Why mlmc_amd.tool.distribution.Distribution.estimate_density has no golden vector: the reference's method
+    (distribution.py:159-181) calls `self._initialize_params(tol)`, whose signature is `(self, size, tol=None)` and which
+    asserts `tol is not None` (:216-223).  Read from the reference's source when it is present (build container only)."""
+    path = "/root/reference/mlmc/tool/distribution.py"
+    if not os.path.exists(path):
+        pytest.skip("reference sources are not present on this machine")
+    src = open(path).read()
+    body = src[src.index("def estimate_density(self, tol=None):"):src.index("def density(self, value, moments_fn=None):")]
+    assert "self._initialize_params(tol)" in body
+    init = src[src.index("def _initialize_params(self, size, tol=None):"):src.index("def extend_size(self, new_size):")]
+    assert "assert tol is not None" in init
