@@ -20,7 +20,7 @@
 namespace mlmc {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-#ifdef MLMC_PROF_COV   // diagnostic build only (tools/dev/prof_cov.hip): per-wave shader cycles of the phases and barrier waits
+#ifdef MLMC_PROF_COV   // diagnostic build only (tools/prof_cov.hip): per-wave shader cycles of the phases and barrier waits
 __device__ unsigned long long *g_prof_cov;
 #define MLMC_COV_STAMP(slot)                                      \
     {                                                             \
@@ -476,7 +476,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     constexpr int STRIDE = BATCH + 2;            // == 2 (mod 32) doubles: conflict-free fragment reads
     // The evaluators are the first waves: they own fewer tiles of a symmetric matrix than the others.  (Waves 2-3 as
     // evaluators of 64-pair batches: +5 % on a mean-only pair level, same-box A/B.  Which SIMD a wave runs on rotates from workgroup to
-    // workgroup -- HW_ID histogram in tools/dev/prof_cov.hip -- so no assignment balances the SIMDs of a CU exactly.)
+    // workgroup -- HW_ID histogram in tools/prof_cov.hip -- so no assignment balances the SIMDs of a CU exactly.)
     constexpr bool evaluator = BLK ? (W == 1) : (W < COV_T4_BATCH / 32);
     constexpr int EW = BLK ? 0 : W;              // index of this wave among the evaluators
     const int samp = PAIR ? (EW * 32 + (lane & 31)) : (EW * 64 + lane);
@@ -484,7 +484,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     const double *__restrict__ src = is_coarse ? coarse : fine;
     // (Measured and not adopted: writing d = f - c and s = f + c instead of f and c -- one half-wave exchange and one add per
     // term in the evaluator lanes save the four waves of phase 2 eight adds per k-step, but the exchange sits in the
-    // evaluation's dependent chain: +9.6 % on a pair level, same-box A/B, tools/dev/gpu_cov_ab_dev.py.)
+    // evaluation's dependent chain: +9.6 % on a pair level, same-box A/B, tools/kbench.py.)
     double *__restrict__ dst = is_coarse ? lds_c : lds_f;
     int n_keep = 0, n_rm = 0;
 
@@ -502,7 +502,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #endif
     // rank of the workgroup among the COV_T4_WGS that share its CU: the dispatcher deals the workgroups of a full grid
     // (launch_cov_accum: COV_T4_WGS per CU) round-robin over the CUs, so the partners of block b are b + n_cu, b + 2 n_cu, ...
-    // (checked with HW_ID in tools/dev/prof_cov.hip); all four waves of a workgroup share the rank
+    // (checked with HW_ID in tools/prof_cov.hip); all four waves of a workgroup share the rank
     constexpr bool RANKS = MODE == 0 && PAIR;      // rotating priorities (see MLMC_COV_MFMA_PRIO)
     const unsigned per_round = gridDim.x >= (unsigned)COV_T4_WGS ? gridDim.x / (unsigned)COV_T4_WGS : 1u;
     const unsigned prio_slot = (blockIdx.x / per_round) % (unsigned)COV_T4_WGS;

@@ -160,7 +160,7 @@ int launch_mask(const mlmc_accum *a, const double *d_f, const double *d_c, int64
 // (coarse), sub, add, fma = 7 fp64 instructions (level 0: 4).
 // ------------------------------------------------------------------------------------------
 #ifdef MLMC_PROF
-__device__ unsigned long long *g_prof;   // tools/dev/prof_moments.hip
+__device__ unsigned long long *g_prof;   // tools/prof_moments.hip
 #endif
 constexpr int MAX_SEG = 16;
 constexpr int PRIO_SLICE_BITS = 16;   // 65536 cycles = 27 us at 2.4 GHz (A/B of 13..17 on one box: 16 and 17 best by ~1 %)

@@ -36,7 +36,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ
 echo "pmc c2 done" >> $O/progress.txt
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_c6 -- python3 bench.py --config 6 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_c6.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_c6 -- python3 bench.py --config 6 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_c6.log 2>&1
-# the moments pass of the default line (term-split kernel, R = 64): its own SQ counters on the stand-alone estimate
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_m64 -- python3 tools/dev/gpu_split_time_dev.py > $O/pmc_sq_m64.log 2>&1
+# the moments kernels alone (term-split kernel R = 64 mean + variance; mean-only 127 terms): their own SQ counters
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_m64 -- python3 tools/moments_only.py > $O/pmc_sq_m64.log 2>&1
 echo done >> $O/progress.txt
 echo done

@@ -3,9 +3,9 @@
 // the barrier behind it -- averaged, per wave index, with the SIMD each wave ran on; wall time of the workgroups by wave slot,
 // by rank on the CU (blockIdx / 256) and by XCD with its clock.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DMLMC_PROF_COV -I include -I mlmc_amd/csrc
-//        tools/dev/prof_cov.hip mlmc_amd/csrc/api.hip mlmc_amd/csrc/moments.hip mlmc_amd/csrc/maxent.hip mlmc_amd/csrc/select.hip
-//        mlmc_amd/csrc/expr.hip mlmc_amd/csrc/expr_jit.hip mlmc_amd/csrc/synth.hip -ldl -o tools/dev/prof_cov
-#include "../../mlmc_amd/csrc/cov.hip"
+//        tools/prof_cov.hip mlmc_amd/csrc/api.hip mlmc_amd/csrc/moments.hip mlmc_amd/csrc/maxent.hip mlmc_amd/csrc/select.hip
+//        mlmc_amd/csrc/expr.hip mlmc_amd/csrc/expr_jit.hip mlmc_amd/csrc/synth.hip -ldl -o tools/prof_cov
+#include "../mlmc_amd/csrc/cov.hip"
 #include <algorithm>
 #include <cstdio>
 #include <random>
@@ -27,7 +27,7 @@ static void run(const char *name, const BasisParams &bp, const double *f, const 
         if constexpr (T == 4)
             hipLaunchKernelGGL((k_cov_accum_t4<MLMC_LEGENDRE, PAIR, MODE, 0>), dim3(blocks), dim3(256), 0, 0, bp, f, PAIR ? c : nullptr, nullptr, n, bp.size, partials, nullptr);
         else
-            hipLaunchKernelGGL((k_cov_accum<MLMC_LEGENDRE, T, PAIR, MODE>), dim3(blocks), dim3(256), 0, 0, bp, f, PAIR ? c : nullptr, nullptr, n, bp.size, partials, nullptr);
+            hipLaunchKernelGGL((k_cov_accum<MLMC_LEGENDRE, T, PAIR, MODE>), dim3(blocks), dim3(256), 0, 0, bp, f, PAIR ? c : nullptr, nullptr, n, bp.size, partials, nullptr, 0, 0);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);

@@ -1,7 +1,7 @@
 // Diagnostic (not part of the library): per-wave time stamps of k_moments_accum<LEGENDRE, 32> on the configs[1] shape.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DMLMC_PROF -I include -I mlmc_amd/csrc
-//        tools/dev/prof_moments.hip mlmc_amd/csrc/api.hip mlmc_amd/csrc/cov.hip mlmc_amd/csrc/maxent.hip mlmc_amd/csrc/select.hip
-#include "../../mlmc_amd/csrc/moments.hip"
+//        tools/prof_moments.hip mlmc_amd/csrc/api.hip mlmc_amd/csrc/cov.hip mlmc_amd/csrc/maxent.hip mlmc_amd/csrc/select.hip
+#include "../mlmc_amd/csrc/moments.hip"
 #include <algorithm>
 #include <cstdio>
 #include <random>

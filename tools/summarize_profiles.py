@@ -46,7 +46,7 @@ for cfg in ("c2", "c3", "c6", "c5", "cd"):
             if kind == "sq_m64":
                 if "k_moments_accum" not in k:
                     continue
-                k = k + " [stand-alone moments estimates, tools/dev/gpu_split_time_dev.py]"
+                k = k + " [stand-alone moments estimates, tools/moments_only.py]"
                 e = summary.setdefault(k, dict(meta[k.split(" [")[0]]))
             else:
                 e = summary.setdefault(k, dict(meta[k]))
