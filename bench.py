@@ -682,7 +682,9 @@ def pdf_solve_timing(fn, L, data, LevelAccumulator, level_stats):
             "first_estimate_chain_ms": round(c1, 3), "n_moments_in": fn.size, "n_moments_orthogonal": int(ortho.size),
             "estimate_chain": ("one mean-only moments pass of {} terms; covariance mean by product linearisation, orthogonal-moments "
                                "means from the same sums".format(ext.size) if ext is not None else
-                               "matrix-core covariance pass (mean only) + moments pass over the orthogonal moments"),
+                               ("banded covariance-mean pass of the spline moments (k_spline_band_accum, no matrix cores) + moments pass "
+                                "over the orthogonal moments" if type(fn).__name__ == "Spline" else
+                                "matrix-core covariance pass (mean only) + moments pass over the orthogonal moments")),
             "nit": int(res.nit), "grad_norm": float(res.fun_norm), "success": bool(res.success)}
 
 

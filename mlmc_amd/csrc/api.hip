@@ -329,7 +329,8 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     // only the passes that exist solely for the second moments are skipped: the three-Gram covariance pass becomes one
     // Gram matrix, the diff-Gram pass of TransformedMoments disappears; plain moments keep their (free) sum of squares
     // covariance from materialised values: TransformedMoments, and plain bases beyond the 128 moments of the in-register kernels
-    a->cov_from_values = mode == MLMC_MODE_COV && (b->out_size > 0 || b->p.size > 128);
+    const bool spline_band = mode == MLMC_MODE_COV && mean_only && b->out_size == 0 && b->p.kind == MLMC_SPLINE && b->p.size <= SPLINE_BAND_MAX_R;
+    a->cov_from_values = mode == MLMC_MODE_COV && (b->out_size > 0 || (b->p.size > 128 && !spline_band));
     a->mean_only = mean_only && ((mode == MLMC_MODE_COV && !a->cov_from_values) || (mode == MLMC_MODE_MOMENTS && b->out_size > 0));
     // plain polynomial moments with 64 < R <= 128: the mean-only form of the term-split kernel covers them in ONE pass
     // (moments.hip, k_moments_accum_split<..., SQ = false>); every other plain size keeps its free sums of squares

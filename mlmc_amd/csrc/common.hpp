@@ -16,6 +16,7 @@ constexpr int ACC_THREADS = 256;   // 4 waves, one per SIMD of a CU
 #define MLMC_TERMS_PER_PASS 64
 #endif
 constexpr int MAX_TERMS_PER_PASS = MLMC_TERMS_PER_PASS;
+constexpr int SPLINE_BAND_MAX_R = 256;   // banded mean-only covariance of spline moments (cov.hip): 4 x 5 x (R + 8) doubles of LDS
 
 // ---- error plumbing ---------------------------------------------------------------------
 void set_error(const std::string &msg);

@@ -873,6 +873,168 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Mean of the covariance of SPLINE moments without the matrix cores.  At most four cubic B-splines are non-zero at a point, so
+// phi_i phi_j vanishes identically for |i - j| > 3 (i, j >= 1; phi_0 = 1 gives row / column 0 = the plain moments): the R x R
+// level sums are a 7-diagonal band plus one row, 14 numbers per value instead of a dense 128 x 128 Gram update.  Like
+// k_spline_accum every wave keeps a private table in LDS -- [r][delta] = sum B_r B_(r+delta), delta = 0..3, and [r][4] = sum B_r --
+// and adds to it with ds_add_f64 (fine values +, coarse values -; both in one span: the differences, 14 atomics per pair);
+// the four tables are summed in a fixed order, the grid reduction scatters the band into the dense G0 (both triangles).
+// 1.25e7 samples x 128 moments, mean only: the dense MFMA pass took 7.1 ms.
+// ------------------------------------------------------------------------------------------
+constexpr int BAND_W = 5;
+template <bool PAIR>
+__global__ __launch_bounds__(256) void k_spline_band_accum(BasisParams bp, const double *__restrict__ fine,
+                                                          const double *__restrict__ coarse, const uint8_t *__restrict__ mask,
+                                                          int64_t n, int R, double *__restrict__ partials,
+                                                          int64_t *__restrict__ pcounts) {
+    extern __shared__ double band_tab[];           // [4 waves][R + 8][BAND_W]
+    __shared__ int ldc[4][2];
+    const int RP8 = R + 8;
+    fine += (int64_t)blockIdx.y * n;
+    if (PAIR) coarse += (int64_t)blockIdx.y * n;
+    partials += (int64_t)blockIdx.y * gridDim.x * (BAND_W * R);
+    if (blockIdx.y) pcounts = nullptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * RP8 * BAND_W; i += 256) band_tab[i] = 0.0;
+    __syncthreads();
+    double *__restrict__ tab = band_tab + (size_t)wave * RP8 * BAND_W;
+    int n_keep = 0, n_rm = 0;
+    const int64_t T = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += T) {
+        bool kf, kc = true;
+        const double tf = transform_value(bp, fine[i], kf);
+        double tc = 0.0;
+        if (PAIR) tc = transform_value(bp, coarse[i], kc);
+        const bool keep = kf && kc && (!mask || mask[i] != 0);
+        n_keep += (int)keep;
+        n_rm += (int)!keep;
+        if (!keep) continue;
+        TermGen<MLMC_SPLINE> gf, gc;
+        gf.init(tf, 1.0, bp);
+        const double nf[4] = {gf.n0, gf.n1, gf.n2, gf.n3};
+        double nc[4] = {0.0, 0.0, 0.0, 0.0};
+        bool same = false;
+        if (PAIR) {
+            gc.init(tc, 1.0, bp);
+            nc[0] = gc.n0; nc[1] = gc.n1; nc[2] = gc.n2; nc[3] = gc.n3;
+            same = gc.k == gf.k;
+        }
+        // fine value (and, in the same span, minus the coarse value)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = gf.k + j;
+            if (r < 1) continue;                                // B_0 is replaced by phi_0 = 1
+            double *__restrict__ row = tab + (size_t)r * BAND_W;
+            atomicAdd(&row[4], same ? nf[j] - nc[j] : nf[j]);
+#pragma unroll
+            for (int j2 = j; j2 < 4; ++j2)
+                atomicAdd(&row[j2 - j], same ? __builtin_fma(nf[j], nf[j2], -(nc[j] * nc[j2])) : nf[j] * nf[j2]);
+        }
+        if (PAIR && !same) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = gc.k + j;
+                if (r < 1) continue;
+                double *__restrict__ row = tab + (size_t)r * BAND_W;
+                atomicAdd(&row[4], -nc[j]);
+#pragma unroll
+                for (int j2 = j; j2 < 4; ++j2) atomicAdd(&row[j2 - j], -(nc[j] * nc[j2]));
+            }
+        }
+    }
+    n_keep = wave_sum_i(n_keep);
+    n_rm = wave_sum_i(n_rm);
+    if (lane == 0) { ldc[wave][0] = n_keep; ldc[wave][1] = n_rm; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < BAND_W * R; j += 256) {
+        const int o = j;                                         // [r][w], r < R
+        partials[(int64_t)blockIdx.x * (BAND_W * R) + j] =
+            ((band_tab[o] + band_tab[(size_t)RP8 * BAND_W + o]) + band_tab[(size_t)2 * RP8 * BAND_W + o]) + band_tab[(size_t)3 * RP8 * BAND_W + o];
+    }
+    if (pcounts && threadIdx.x < 2)
+        pcounts[(int64_t)blockIdx.x * 2 + threadIdx.x] = ldc[0][threadIdx.x] + ldc[1][threadIdx.x] + ldc[2][threadIdx.x] + ldc[3][threadIdx.x];
+}
+
+// Band partials [nblocks][R][BAND_W] (per component) -> dense G0 [RP][RP]: fixed-order sums (16 columns per workgroup, 64 row
+// groups, like k_reduce_cov), both triangles; row / column 0 from the plain sums; G0[0][0] += kept samples at level 0
+// (phi_0 phi_0 = 1; the differences of a pair level vanish).  The last workgroup in x sums the sample counts.
+__global__ __launch_bounds__(1024) void k_reduce_band(const double *__restrict__ partials, const int64_t *__restrict__ pcounts, int nblocks,
+                                                     int R, int RP, double *__restrict__ totals, int64_t comp_stride,
+                                                     int64_t *__restrict__ counts, int corner) {
+    __shared__ double lds[64][17];
+    __shared__ long long lc[16][2];
+    const int width = BAND_W * R;
+    const int n_col_groups = (width + 15) / 16;
+    totals += (int64_t)blockIdx.y * comp_stride;
+    if ((int)blockIdx.x == n_col_groups) {          // the counting workgroup: kept / removed samples of this launch
+        long long a = 0, b = 0;
+        for (int i = threadIdx.x; i < nblocks; i += 1024) { a += pcounts[2 * i]; b += pcounts[2 * i + 1]; }
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+        if ((threadIdx.x & 63) == 0) { lc[threadIdx.x >> 6][0] = a; lc[threadIdx.x >> 6][1] = b; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a = 0; b = 0;
+            for (int w = 0; w < 16; ++w) { a += lc[w][0]; b += lc[w][1]; }
+            if (counts && blockIdx.y == 0) { counts[0] += a; counts[1] += b; }
+            if (corner) totals[0] += (double)a;
+        }
+        return;
+    }
+    partials += (int64_t)blockIdx.y * nblocks * width;
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + c;
+    double acc = 0.0;
+    if (col < width)
+        for (int b = g; b < nblocks; b += 64) acc += partials[(int64_t)b * width + col];
+    lds[g][c] = acc;
+    __syncthreads();
+    if (g == 0 && col < width) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) v += lds[k][c];
+        const int r = col / BAND_W, w = col % BAND_W;
+        if (r >= 1) {
+            if (w == 4) {
+                totals[r] += v;
+                totals[(int64_t)r * RP] += v;
+            } else if (r + w < R) {
+                totals[(int64_t)r * RP + r + w] += v;
+                if (w) totals[(int64_t)(r + w) * RP + r] += v;
+            }
+        }
+    }
+}
+
+static int launch_spline_band(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask, int64_t n,
+                              bool count, int ncomp) {
+    hipStream_t st = rt().stream;
+    const int R = a->R;
+    const bool pair = d_c != nullptr;
+    int blocks = rt().n_cu * 4;
+    const int64_t want = (n + 255) / 256;
+    if (want < blocks) blocks = (int)want;
+    if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * BAND_W * R * ncomp)) return rc;
+    if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
+    const size_t lds = sizeof(double) * 4 * (size_t)(R + 8) * BAND_W;
+    const BasisParams &bp = a->basis->p;
+    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width;
+    if (int rc = timing_begin(a)) return rc;
+    // the kept count is needed for G0[0][0] at level 0 even when another kernel (k_mask) has counted the samples already
+    if (pair)
+        hipLaunchKernelGGL(k_spline_band_accum<true>, dim3(blocks, ncomp), dim3(256), lds, st, bp, d_f, d_c, d_mask, n, R, a->d_partials, a->d_pcounts);
+    else
+        hipLaunchKernelGGL(k_spline_band_accum<false>, dim3(blocks, ncomp), dim3(256), lds, st, bp, d_f, d_c, d_mask, n, R, a->d_partials, a->d_pcounts);
+    MLMC_HIP_CHECK(hipGetLastError());
+    if (int rc = timing_end(a)) return rc;
+    a->launches += 1;
+    a->alg_bytes += (int64_t)n * (pair ? 16 : 8) * ncomp;
+    hipLaunchKernelGGL(k_reduce_band, dim3((BAND_W * R + 15) / 16 + 1, ncomp), dim3(1024), 0, st, a->d_partials, a->d_pcounts, blocks, R, a->RP,
+                       totals, a->int_width, count ? a->d_counts + 2 * (int64_t)level : (int64_t *)nullptr, pair ? 0 : 1);
+    MLMC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // 16 x 16 output tiles one sample (pair) contributes to in one block launch -- the kernels' tile lists above:
 // gram_mode 0 = G0, G1, G2 (level 0: two symmetric matrices), 1 = D^T D (symmetric), 2 = G0 only (level 0: F^T F, symmetric).
 // x 512 = executed matrix-core flops per sample (mlmc_accum_kernel_flops).
@@ -890,6 +1052,8 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     const bool diff_gram_only = gram_mode == 1;   // gram_mode: 0 = G0, G1, G2; 1 = D^T D into the moments' Gram slot; 2 = G0 only
     if (n == 0) return 0;
     const int R = a->R;
+    if (a->basis->p.kind == MLMC_SPLINE && gram_mode == 2 && R <= SPLINE_BAND_MAX_R)
+        return launch_spline_band(a, level, comp, d_f, d_c, d_mask, n, count, ncomp);      // banded: no matrix cores needed
     if (R > 128) return fail("covariance accumulation in registers covers 128 moments; larger bases go through launch_cov_from_values");
     hipStream_t st = rt().stream;
     const int T = (R <= 16) ? 1 : (R <= 32 ? 2 : 4);

@@ -743,6 +743,48 @@ def test_spline_moments(hip):
         assert close(l_vars, ref.l_vars, 1e-6 * np.max(ref.l_vars, axis=1, keepdims=True), TOL)
 
 
+@pytest.mark.parametrize("R", [4, 8, 37, 128, 200])
+def test_spline_covariance_mean_is_banded(hip, R):
+    """Mean-only covariance of spline moments: phi_i phi_j = 0 for |i - j| > 3, so the level sums are accumulated as a band
+    (k_spline_band_accum, 14 LDS atomics per value, no matrix cores) -- against the dense matrix-core pass of the same library
+    (mean + variance; R > 128: from materialised values) and the scipy-BSpline oracle; pairs in one span / in different
+    spans, level 0, masked samples, a vector quantity."""
+    from mlmc_amd import Spline
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-3.7, 3.7)
+    levels = level_arrays([9001, 5000, 2501], [0.9, 0.07, 0.01], 1, 17)       # level 1: a coarse step large enough to cross spans
+    fn = Spline(R, dom)
+    band = _run_accum(fn, levels, mode=LevelAccumulator.COV | 0)                # dense, for the counts
+    acc = LevelAccumulator(fn, len(levels), LevelAccumulator.COV, mean_only=True)
+    for l, (f, c) in enumerate(levels):
+        acc.push(l, f[0], None if c is None else c[0])
+    n1, r1, s1, sp1 = acc.finalize()
+    n0, r0, s0, sp0 = band
+    assert np.array_equal(n0, n1) and np.array_equal(r0, r1) and np.all(np.isnan(sp1))
+    scale = np.sqrt(np.abs(sp0) * n0[:, None]) + 1e-300
+    assert np.max(np.abs(s1 - s0) / np.maximum(np.abs(s0), scale)) < 1e-10     # the parity gate (the dense pass forms 1/2 (d s + s d))
+    S = s1.reshape(len(levels), R, R)
+    i, j = np.indices((R, R))
+    off_band = (np.abs(i - j) > 3) & (i > 0) & (j > 0)
+    assert np.all(S[:, off_band] == 0.0) and np.array_equal(S, S.transpose(0, 2, 1))
+    if R <= 37:
+        b = onp.Basis(onp.SPLINE, R, dom)
+        ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.covariance_rows(b, x))
+        assert np.array_equal(n1, ref.n_samples) and np.array_equal(r1, ref.n_rm_samples)
+        rms = np.sqrt(np.abs(ref.sums_sq) * ref.n_samples[:, None])
+        assert np.all(np.abs(s1 - ref.sums) <= 1e-10 * np.maximum(np.abs(ref.sums), rms) + 1e-300)
+    # two components: one mask for both
+    lv2 = level_arrays([3001, 2000], [0.5, 0.07], 2, 11)
+    full = _run_accum(fn, lv2, mode=LevelAccumulator.COV, n_comp=2)
+    acc = LevelAccumulator(fn, 2, LevelAccumulator.COV, n_comp=2, mean_only=True)
+    for l, (f, c) in enumerate(lv2):
+        acc.push(l, f, c)
+    n2, r2, s2, _ = acc.finalize()
+    assert np.array_equal(n2, full[0]) and np.array_equal(r2, full[1])
+    sc2 = np.sqrt(np.abs(full[3]) * full[0][:, None]) + 1e-300
+    assert np.max(np.abs(s2 - full[2]) / np.maximum(np.abs(full[2]), sc2)) < 1e-12
+
+
 def test_covariance_of_transformed_moments(hip):
     """estimate_covariance with a TransformedMoments basis: transformed values are materialised chunk-wise on the device
     and fed to the MFMA covariance kernel; against the oracle (reference form, per-sample matrix product)."""
