@@ -842,7 +842,7 @@ def _linearized_basis(fn):
     return ext
 
 
-def _sums_from_linearized_memo(fn, key):
+def _sums_from_linearized_memo(fn, key, owner):
     """Level sums of TransformedMoments(base, T) from the kept sums of a linearised covariance-mean estimate of `base` over the
     same samples (same quantity rows, same level stamps, same cache generation): the transformed moments are linear in the
     base moments, sum_n (T d_n) = T sum_n d_n, and the keep / drop decision is the base transform's.  This is the second
@@ -851,8 +851,8 @@ def _sums_from_linearized_memo(fn, key):
     if not isinstance(fn, TransformedMoments) or key is None:
         return None
     memo = fn._base.__dict__.get("_lin_memo")
-    if memo is None or memo["key"] != key or fn._base_matrix.shape[1] != memo["R"]:
-        return None
+    if memo is None or memo["key"] != key or fn._base_matrix.shape[1] != memo["R"] or memo["owner"]() is not owner:
+        return None                       # (the key carries id(owner): the weak reference rules out a recycled id)
     L, n_comp, K, R = memo["sums"].shape[0], memo["n_comp"], memo["K"], memo["R"]
     base = memo["sums"].reshape(L * n_comp, K)[:, :R]
     return memo["n"].copy(), memo["n_rm"].copy(), (base @ fn._base_matrix.T).reshape(L, -1), n_comp
@@ -974,7 +974,7 @@ def _estimate_mean(quantity, group, variance):
     if n_collected is not None and subsample_params is None and group is None and not engine._dist_group_active(group):
         memo_key = (ident, n_collected, _cache_generation)
     if not variance and mode == engine.LevelAccumulator.MOMENTS and lin_fn is None and fn is not None:
-        short = _sums_from_linearized_memo(fn, memo_key)
+        short = _sums_from_linearized_memo(fn, memo_key, owner)
         if short is not None:
             n_samples, n_rm_samples, sums, n_comp = short
             return _finish_estimate(quantity, fn, n_levels, n_comp, rows_out, n_samples, n_rm_samples, sums,
@@ -1057,7 +1057,7 @@ def _estimate_mean(quantity, group, variance):
     if lin_fn is not None:
         if memo_key is not None:
             lin_fn.__dict__["_lin_memo"] = dict(key=memo_key, n=n_samples.copy(), n_rm=n_rm_samples.copy(), sums=sums.copy(),
-                                                n_comp=n_comp, K=fn.size, R=lin_fn.size)
+                                                n_comp=n_comp, K=fn.size, R=lin_fn.size, owner=_BlockMeta._ref(owner))
         sums = linearize.covariance_sums_from_moment_sums(lin_fn, sums, n_comp)
         sums_sq = np.full_like(sums, np.nan)                       # mean only: the variances were not asked for
         fn = lin_fn
