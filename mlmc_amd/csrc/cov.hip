@@ -100,20 +100,10 @@ constexpr int COV_T4_BATCH = MLMC_COV_T4_BATCH;   // pairs per batch of the 64-t
 constexpr int COV_T4_WGS = MLMC_COV_T4_WGS;       // its workgroups per CU
 // samples per batch: small tiles evaluated from raw samples take 128 sample pairs, or 256 samples at level 0 (one LDS array
 // instead of two, and all four waves evaluate at both kinds of level); everything else 64
-// Mean-only covariance (MODE 2) of a diagonal 64 x 64 block: the k-sliced mapping of the small tiles -- a wave owns a quarter of
-// the batch's samples and ALL 16 tiles (128 accumulator registers, two workgroups per CU) -- instead of a 2 x 2 tile block per
-// wave: per 16 matrix instructions 8 LDS reads and 8 adds instead of 16-32 of each (0: the wave-specialised kernel).
-#ifndef MLMC_COV_MEAN_SLICED4
-#define MLMC_COV_MEAN_SLICED4 0
-#endif
 #ifndef MLMC_COV_WIDE_BATCH
 #define MLMC_COV_WIDE_BATCH 32      // pairs per batch of the two-window (off-diagonal) blocks: 70 KB of LDS, two workgroups per
                                     // CU (64 pairs, 135 KB, one per CU: +3 % with variances, +5 % mean-only at R = 128)
 #endif
-// k-sliced mapping (a wave owns a quarter of the batch's samples and all tiles of the block; four partial rows per workgroup)
-__host__ __device__ constexpr bool cov_sliced(int T, int mode, bool wide, bool vals) {
-    return !wide && (T <= 2 || (T == 4 && mode == 2 && MLMC_COV_MEAN_SLICED4 && !vals));
-}
 __host__ __device__ constexpr int cov_batch(int T, bool wide, bool vals, bool pair = true) {
     return (T <= 2 && !wide && !vals) ? (pair ? 128 : 256) : ((wide && pair && !vals) ? MLMC_COV_WIDE_BATCH : 64);
 }
@@ -171,7 +161,7 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
     // blockIdx.y = component of a vector quantity ([M][n] arrays, one mask for all): its own samples and partial rows
     fine += (int64_t)blockIdx.y * n;
     if (PAIR) coarse += (int64_t)blockIdx.y * n;
-    partials += (int64_t)blockIdx.y * gridDim.x * (cov_sliced(T, MODE, BI != BJ, VALS) ? 4 : 4 / T) * (((MODE == 0) ? 3 : 1) * (16 * T) * (16 * T));
+    partials += (int64_t)blockIdx.y * gridDim.x * ((T <= 2 && BI == BJ) ? 4 : 4 / T) * (((MODE == 0) ? 3 : 1) * (16 * T) * (16 * T));
     if (blockIdx.y) pcounts = nullptr;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -182,7 +172,7 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
     // lane % 16, sample 4 ks + lane / 16) in both operand layouts), so one read of the fine / coarse values of the T
     // row blocks feeds T x T MFMAs per Gram matrix -- a third of the LDS traffic of the row-tile mapping below, which at
     // these tile sizes was as busy as the matrix pipe itself (1.5 KB of ds_read per MFMA against 2 KB per 64 cycles).
-    constexpr bool SLICED = cov_sliced(T, MODE, WIDE, VALS);
+    constexpr bool SLICED = (T <= 2) && !WIDE;
     constexpr int TI = SLICED ? T : 1;
     v4f64 acc[NG][TI][T];
 #pragma unroll
@@ -781,7 +771,7 @@ template <int KIND, int T, int MODE, int BI, int BJ>
 static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, int ncomp, const double *d_f, const double *d_c,
                         const uint8_t *d_mask, int64_t n, int R, double *partials, int64_t *pcounts) {
     hipStream_t st = rt().stream;
-    if constexpr (T == 4 && BI == BJ && !(BI == 0 && cov_sliced(4, MODE, false, false))) {   // diagonal 64 x 64 block: wave-specialised kernel (symmetric tiles used where they exist)
+    if constexpr (T == 4 && BI == BJ) {   // diagonal 64 x 64 block: wave-specialised kernel (symmetric tiles used where they exist)
         if (pair)
             hipLaunchKernelGGL((k_cov_accum_t4<KIND, true, MODE, BI>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
         else
@@ -1071,23 +1061,21 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     const int NG = gram_mode == 0 ? 3 : 1;
     const int NB = (R + 63) / 64;          // 64 x 64 output blocks per dimension
     const bool pair = d_c != nullptr;
+    const int64_t bsz = T == 4 ? (pair ? COV_T4_BATCH : 2 * COV_T4_BATCH) : cov_batch(T, false, false, pair);
+    const int64_t n_batches = (n + bsz - 1) / bsz;
     const size_t width = (size_t)NG * NT * NT;
     const BasisParams &bp = a->basis->p;
     double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0);
     for (int bi = 0; bi < NB; ++bi)
         for (int bj = 0; bj < NB; ++bj) {
             if (!pair && bj < bi) continue;   // level 0: symmetric matrices, block (bj, bi) is mirrored by the reduction
-            // mean-only, first diagonal block: the k-sliced generic kernel (launch_cov_t makes the same choice at compile time)
-            const bool sliced4 = T == 4 && bi == 0 && bj == 0 && cov_sliced(4, gram_mode, false, false);
-            const int64_t bsz = (T == 4 && !sliced4) ? (pair ? COV_T4_BATCH : 2 * COV_T4_BATCH) : cov_batch(T, false, false, pair);
-            const int64_t n_batches = (n + bsz - 1) / bsz;
             // workgroups per CU: one for the two-window blocks (135 KB of LDS), four for a single 16-term tile (33 KB each:
             // -11..15 % time against two), two otherwise
-            int blocks = rt().n_cu * ((bi != bj) ? ((pair && MLMC_COV_WIDE_BATCH < 64) ? 2 : 1) : (T == 1 ? 4 : ((T == 4 && !sliced4) ? COV_T4_WGS : 2)));
+            int blocks = rt().n_cu * ((bi != bj) ? ((pair && MLMC_COV_WIDE_BATCH < 64) ? 2 : 1) : (T == 1 ? 4 : (T == 4 ? COV_T4_WGS : 2)));
             // small chunks: at least four batches per workgroup -- every workgroup leaves NSL partial matrices behind and the
             // reduction reads them all (a 24-component quantity of 10^5 samples spent more time there than in the MFMAs)
             if ((n_batches + 3) / 4 < blocks) blocks = (int)((n_batches + 3) / 4);
-            const int n_slices = (T <= 2 || sliced4) ? 4 : NSL;     // partial rows per workgroup (k_cov_accum: SLICED)
+            const int n_slices = T <= 2 ? 4 : NSL;     // partial rows per workgroup (k_cov_accum: SLICED)
             if (int rc = ensure((void **)&a->d_partials, &a->partials_cap, sizeof(double) * (size_t)blocks * n_slices * width * ncomp)) return rc;
             if (int rc = ensure((void **)&a->d_pcounts, &a->pcounts_cap, sizeof(int64_t) * (size_t)blocks * 2)) return rc;
             const bool do_count = count && bi == 0 && bj == 0;
