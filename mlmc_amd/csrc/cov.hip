@@ -100,6 +100,17 @@ constexpr int COV_T4_BATCH = MLMC_COV_T4_BATCH;   // pairs per batch of the 64-t
 constexpr int COV_T4_WGS = MLMC_COV_T4_WGS;       // its workgroups per CU
 // samples per batch: small tiles evaluated from raw samples take 128 sample pairs, or 256 samples at level 0 (one LDS array
 // instead of two, and all four waves evaluate at both kinds of level); everything else 64
+// 64-term kernel: the samples of a batch sit in LDS in the order the fragment reads want them -- the two samples a lane needs
+// in k-steps 2j and 2j + 1 next to each other -- so one ds_read_b128 fetches a lane's operand values for TWO k-steps (half
+// the LDS instructions of phase 2).  0: one ds_read_b64 per k-step (round 2).
+#ifndef MLMC_COV_B128
+#define MLMC_COV_B128 1
+#endif
+#ifndef MLMC_COV_B128_PAD
+#define MLMC_COV_B128_PAD (MLMC_COV_B128 ? 4 : 2)
+#endif
+// position of sample s of a batch in its LDS row: s = 8 j + 4 h + g (k-step 2 j + h, lane group g) -> 8 j + 2 g + h
+__device__ __forceinline__ int cov_t4_pos(int s) { return MLMC_COV_B128 ? ((s & ~7) | ((s & 3) << 1) | ((s >> 2) & 1)) : s; }
 #ifndef MLMC_COV_WIDE_BATCH
 #define MLMC_COV_WIDE_BATCH 32      // pairs per batch of the two-window (off-diagonal) blocks: 70 KB of LDS, two workgroups per
                                     // CU (64 pairs, 135 KB, one per CU: +3 % with variances, +5 % mean-only at R = 128)
@@ -473,13 +484,16 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     // COV_T4_BATCH / 32 evaluator waves either way (pairs: lane = (sample, fine | coarse); level 0: lane = sample), so the
     // evaluation phase is spread over the same share of the workgroup at both kinds of level.
     constexpr int BATCH = PAIR ? COV_T4_BATCH : 2 * COV_T4_BATCH;
-    constexpr int STRIDE = BATCH + 2;            // == 2 (mod 32) doubles: conflict-free fragment reads
+    // row stride in doubles: == 2 (mod 32) makes the 64-bit fragment reads conflict-free; the 128-bit reads (16 lanes per LDS
+    // cycle, four banks each) want == 4 (mod 32): 8 row + 4 g (mod 64) is then a different bank quad for every lane of a group
+    constexpr int STRIDE = BATCH + MLMC_COV_B128_PAD;
     // The evaluators are the first waves: they own fewer tiles of a symmetric matrix than the others.  (Waves 2-3 as
     // evaluators of 64-pair batches: +5 % on a mean-only pair level, same-box A/B.  Which SIMD a wave runs on rotates from workgroup to
     // workgroup -- HW_ID histogram in tools/prof_cov.hip -- so no assignment balances the SIMDs of a CU exactly.)
     constexpr bool evaluator = BLK ? (W == 1) : (W < COV_T4_BATCH / 32);
     constexpr int EW = BLK ? 0 : W;              // index of this wave among the evaluators
     const int samp = PAIR ? (EW * 32 + (lane & 31)) : (EW * 64 + lane);
+    const int psamp = cov_t4_pos(samp);          // where this sample's values go in the LDS rows
     const bool is_coarse = PAIR && (lane >> 5);
     const double *__restrict__ src = is_coarse ? coarse : fine;
     // (Measured and not adopted: writing d = f - c and s = f + c instead of f and c -- one half-wave exchange and one add per
@@ -524,12 +538,12 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
             TermGen<KIND> g;
             g.init(keep ? t : 0.0, keep ? 1.0 : 0.0, bp);
             if constexpr (KIND == MLMC_SPLINE) {
-                cov_spline_store<NT, STRIDE, TA>(g, dst, samp);
+                cov_spline_store<NT, STRIDE, TA>(g, dst, psamp);
             } else {
 #pragma unroll
                 for (int i = 0; i < N_EVAL; ++i) {
                     const double q = g.next(i);
-                    if (i >= TA) dst[(i - TA) * STRIDE + samp] = q;
+                    if (i >= TA) dst[(i - TA) * STRIDE + psamp] = q;
                 }
             }
         }
@@ -552,6 +566,8 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
         // changed the register allocation of the stand-alone kernel, too; the four pair levels alone in one launch, from a
         // translation unit of its own: -0.3 % -- the end of a launch is not where the time goes.  A static schedule that gives the youngest
         // workgroup of a CU 15 batches where the others get 16: no change.)
+        typedef double v2f64 __attribute__((ext_vector_type(2)));
+        v2f64 f2[4], c2[4];
 #pragma unroll
         for (int ks = 0; ks < BATCH / 4; ++ks) {
             const int col = 4 * ks + (lane >> 4);
@@ -559,11 +575,23 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #pragma unroll
             for (int J = 0; J < 4; ++J) {
                 const int row = 16 * J + (lane & 15);
-                const double f = lds_f[row * STRIDE + col];
+                double f, c = 0.0;
+                if (MLMC_COV_B128) {
+                    // (fully unrolled: `ks` is a constant) one 128-bit read per operand row and PAIR of k-steps
+                    if ((ks & 1) == 0) {
+                        const int base = row * STRIDE + 8 * (ks >> 1) + 2 * (lane >> 4);
+                        f2[J] = *reinterpret_cast<const v2f64 *>(lds_f + base);
+                        if (PAIR) c2[J] = *reinterpret_cast<const v2f64 *>(lds_c + base);
+                    }
+                    f = (ks & 1) ? f2[J].y : f2[J].x;
+                    if (PAIR) c = (ks & 1) ? c2[J].y : c2[J].x;
+                } else {
+                    f = lds_f[row * STRIDE + col];
+                    if (PAIR) c = lds_c[row * STRIDE + col];
+                }
                 d[J] = f;
                 sm[J] = f;
                 if (PAIR) {
-                    const double c = lds_c[row * STRIDE + col];
                     d[J] = f - c;
                     sm[J] = f + c;
                 }
@@ -709,8 +737,8 @@ __global__ __launch_bounds__(256, COV_T4_WGS) void k_cov_accum_t4(BasisParams bp
                                                          const double *__restrict__ fine, const double *__restrict__ coarse,
                                                          const uint8_t *__restrict__ mask, int64_t n, int R,
                                                          double *__restrict__ partials, int64_t *__restrict__ pcounts) {
-    __shared__ double lds_f[64 * ((PAIR ? COV_T4_BATCH : 2 * COV_T4_BATCH) + 2)];       // term-major fine values (level 0: 128 samples)
-    __shared__ double lds_c[PAIR ? 64 * (COV_T4_BATCH + 2) : 1];                      // coarse values
+    __shared__ __attribute__((aligned(16))) double lds_f[64 * ((PAIR ? COV_T4_BATCH : 2 * COV_T4_BATCH) + MLMC_COV_B128_PAD)];   // term-major fine values (level 0: 128 samples)
+    __shared__ __attribute__((aligned(16))) double lds_c[PAIR ? 64 * (COV_T4_BATCH + MLMC_COV_B128_PAD) : 1];                  // coarse values
     __shared__ int ldc[2][2];
     (void)R;
     // blockIdx.y = component of a vector quantity (see k_cov_accum): one partial row [3 or 1][64][64] per workgroup
