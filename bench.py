@@ -247,7 +247,7 @@ def host_formulas(n, s, sp, level_stats):
         return l_means, l_vars, np.sum(l_means, axis=0), np.sum(l_vars / n[:, None], axis=0)
 
 
-def estimate_block(cfg, data, fn, steps_h, ctx, steps, warmup, preroll_ms, config_key, with_moments_pass=False):
+def estimate_block(cfg, data, fn, steps_h, ctx, steps, warmup, preroll_ms, config_key, mean_only=False):
     """One measured workload on resident data -> result dict (value, ms_per_step, roofline, result_check, ...).
     cfg["mode"] == "cov": covariance estimate + regression + re-allocation, the moments' level variances taken from the
     covariance sums (engine.moments_from_covariance)."""
@@ -255,7 +255,7 @@ def estimate_block(cfg, data, fn, steps_h, ctx, steps, warmup, preroll_ms, confi
     from mlmc_amd.estimator import Estimate, estimate_n_samples_for_target_variance
     L, R = cfg["L"], cfg["R"]
     mode = LevelAccumulator.MOMENTS if cfg["mode"] == "moments" else LevelAccumulator.COV
-    acc = LevelAccumulator(fn, L, mode)
+    acc = LevelAccumulator(fn, L, mode, mean_only=mean_only)
     chunks = [(l, data[l][0], data[l][1]) for l in range(L)]
     n_ops = [(1.0 / h) ** 2 * np.log(max(1.0 / h, 2.0)) for h in steps_h]      # synth_simulation.py:133-134
     regress = Estimate(None, None, fn)._all_moments_variance_regression
@@ -507,6 +507,16 @@ def main():
                 m2 = estimate_block(dict(c2, mode="moments"), d2, f2, sh, ctx, 20, 5, 0.0, 3)
                 blk["moments"] = {k: m2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "roofline")}
                 blk["both_ms"] = blk["ms_per_step"] + m2["ms_per_step"]
+                # the MEANS of moments and covariance alone (what Estimate.construct_density reads): one mean-only pass of
+                # 2 R - 1 moments, the covariance means by product linearisation (mlmc_amd/linearize.py) -- no variances
+                from mlmc_amd.quantity import quantity_estimate as qe_
+                ext2 = qe_._linearized_basis(f2)
+                if ext2 is not None:
+                    m3 = estimate_block(dict(c2, mode="moments", R=ext2.size), d2, ext2, sh, ctx, 20, 5, 0.0, 3, mean_only=True)
+                    blk["means_only"] = {"ms_per_step": m3["ms_per_step"], "n_moments_pass": ext2.size,
+                                         "hbm_frac": round((c2["L"] * 2 - 1) * c2["n_per_level"] * 8.0 / (m3["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                                         "note": "level means of the 64 moments AND of their 64 x 64 covariance from ONE pass of 127 moments "
+                                                 "(6 fp64 instructions per term and pair: vector-pipe bound, not HBM)"}
                 blk["hbm_frac_both"] = round((c2["L"] * 2 - 1) * c2["n_per_level"] * 8.0 * 2 / (blk["both_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
                 blk["note"] = ("north_star asks for >= 60 % of the HBM roofline on moments + covariance at R = 64; in fp64 the "
                                "covariance is matrix-core bound (>= 1000 flop/B) and the moments pass VALU bound (56 flop/B): the "
