@@ -479,9 +479,10 @@ def test_covariance_layouts_of_vector_quantity(hip):
         assert close(r.mean.ravel(), ref.mean, 1.0, TOL) and close(r.var.ravel(), ref.var, None, TOL)
 
 
-def test_device_chunk_cache(hip):
+def test_device_chunk_cache(hip, monkeypatch):
     """Repeated estimates of the same quantity read the samples from HBM; appended samples and sub-sampled quantities
     bypass the cache."""
+    monkeypatch.setenv("MLMC_HIP_STREAM_UPLOAD", "1")            # the upload counts below are the level streamer's
     from mlmc_amd import Legendre
     from mlmc_amd.estimator import Estimate
     from mlmc_amd.quantity import quantity_estimate as qe
@@ -940,6 +941,7 @@ def test_device_tree_block_upload_in_estimates(hip, monkeypatch):
     st = make_storage((2600, 1500, 700), chunk_size=1000)
     root = make_root_quantity(st, _spec())
     n_chunks = len(list(st.chunks()))
+    monkeypatch.setenv("MLMC_HIP_STREAM_UPLOAD", "1")            # the upload counts below are the level streamer's
     fn = Legendre(7, (-1.5, 6.0))
     q = root['length'].time_interpolation(1.5)['20'] * np.array([1.0, 0.5]) + root['width'][1]['30']   # reads 6 of 24 rows
     res, uploads = {}, {}
