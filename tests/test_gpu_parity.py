@@ -665,7 +665,12 @@ def _sharded_api_worker(rank, world, port, n_total, steps, out_dir):
         est = Estimate(q, st, Legendre(8, (-12.0, 20.0)))
         means, variances = est.estimate_moments()
         cov, _ = est.estimate_covariance()
-        np.savez(os.path.join(out_dir, f"api_rank{rank}.npz"), means=means, variances=variances, cov=cov)
+        # construct_density over the shards: the linearised covariance-mean pass and the orthogonal-moments pass are both
+        # all-reduced (the kept-sums shortcut of the single-process chain is off under a process group)
+        distr, _, res, _ = est.construct_density(tol=1e-8)
+        dens = distr.density(np.linspace(-12.0, 20.0, 201))
+        np.savez(os.path.join(out_dir, f"api_rank{rank}.npz"), means=means, variances=variances, cov=cov, dens=dens,
+                 ok=np.array(bool(res.success)))
     finally:
         dist.destroy_process_group()
 
@@ -691,11 +696,14 @@ def test_two_rank_estimate_through_the_python_api(hip, tmp_path):
     est = Estimate(q, st, Legendre(8, (-12.0, 20.0)))
     means, variances = est.estimate_moments()
     cov, _ = est.estimate_covariance()
+    distr, _, res, _ = est.construct_density(tol=1e-8)
     r0, r1 = np.load(tmp_path / "api_rank0.npz"), np.load(tmp_path / "api_rank1.npz")
-    for k in ("means", "variances", "cov"):
+    for k in ("means", "variances", "cov", "dens"):
         assert np.array_equal(r0[k], r1[k])
     assert close(r0["means"], means, 1.0, 1e-12) and close(r0["variances"], variances, np.max(variances), 1e-12)
     assert close(r0["cov"], cov, 1.0, 1e-12)
+    assert res.success and bool(r0["ok"])
+    assert np.max(np.abs(r0["dens"] - distr.density(np.linspace(-12.0, 20.0, 201)))) < 1e-7
 
 
 def test_spline_moments(hip):
