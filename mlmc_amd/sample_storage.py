@@ -232,3 +232,91 @@ class Memory(SampleStorage):
 
     def get_level_parameters(self):
         return self._level_parameters
+
+
+class DeviceMemory(SampleStorage):
+    """Samples that already live in HBM (torch CUDA tensors), presented through the SampleStorage interface: a level is a
+    tensor `[M, n, 2]` (fine, coarse pairs of M stored rows; level 0: `[M, n, 1]`), handed over with `set_level_samples`.
+    The estimators read the rows where they are (`device_row`: the same hook `sim.synth_device.SynthDeviceStorage` offers) --
+    nothing crosses PCIe.  Not part of the reference (its storages are host-side); for producers that write their samples
+    on the GPU, and for `bench.py`'s `pdf_solve` block, which times `Estimate.construct_density` on resident samples."""
+
+    def __init__(self):
+        self._levels = {}
+        self._level_parameters = []
+        self._result_specification = []
+        self._n_ops = {}
+        self._level_versions = {}
+
+    def save_global_data(self, result_format, level_parameters=None):
+        self._result_specification = result_format
+        self._level_parameters = level_parameters
+
+    def set_level_samples(self, level_id, pairs):
+        """pairs: torch CUDA tensor [M, n, 2] (level 0: [M, n, 1] or [M, n, 2] with an unused coarse column), float64."""
+        assert pairs.is_cuda and pairs.dim() == 3 and pairs.dtype.is_floating_point
+        if int(level_id) == 0 and pairs.shape[2] == 2:
+            pairs = pairs[:, :, :1]
+        self._levels[int(level_id)] = pairs.contiguous()
+        self._level_versions[int(level_id)] = self._level_versions.get(int(level_id), 0) + 1
+
+    def device_row(self, chunk_spec, stored_row):
+        t = self._levels[int(chunk_spec.level_id)][int(stored_row)]
+        sl = chunk_spec.chunk_slice
+        return t if sl is None else t[sl.start:sl.stop]
+
+    def sample_pairs_level(self, chunk_spec):
+        """Host copy [M, n, 2|1] of a chunk (tests, host-evaluated trees)."""
+        t = self._levels[int(chunk_spec.level_id)]
+        sl = chunk_spec.chunk_slice
+        return (t if sl is None else t[:, sl.start:sl.stop]).cpu().numpy()
+
+    def sample_pairs(self):
+        return [self.sample_pairs_level(ChunkSpec(level_id=l)) for l in sorted(self._levels)]
+
+    def _level_chunks(self, level_id, n_samples=None):
+        total = self._levels[int(level_id)].shape[1]
+        if n_samples is not None:
+            total = min(total, n_samples)
+        yield ChunkSpec(chunk_id=0, chunk_slice=slice(0, total, 1), level_id=level_id)
+
+    def load_result_format(self):
+        return self._result_specification
+
+    def save_result_format(self, res_spec):
+        self._result_specification = res_spec
+
+    def save_n_ops(self, n_ops):
+        for level, (time, n_samples) in n_ops:
+            self._n_ops.setdefault(level, 0)
+            if n_samples != 0:
+                self._n_ops[level] += time / n_samples
+
+    def get_n_ops(self):
+        return [self._n_ops[level] for level in sorted(self._n_ops.keys())]
+
+    def n_finished(self):
+        return np.array([self._levels[l].shape[1] for l in sorted(self._levels)], dtype=float)
+
+    def get_level_ids(self):
+        return sorted(self._levels.keys())
+
+    def get_n_levels(self):
+        return len(self._levels)
+
+    def get_n_collected(self):
+        return [int(self._levels[l].shape[1]) for l in sorted(self._levels)]
+
+    def get_level_parameters(self):
+        return self._level_parameters
+
+    def unfinished_ids(self):
+        return []
+
+    def _not_stored(self, *args, **kwargs):
+        raise NotImplementedError("DeviceMemory takes whole levels: set_level_samples")
+
+    save_samples = save_scheduled_samples = _not_stored
+
+    def load_scheduled_samples(self):
+        return {}

@@ -479,6 +479,49 @@ def test_covariance_layouts_of_vector_quantity(hip):
         assert close(r.mean.ravel(), ref.mean, 1.0, TOL) and close(r.var.ravel(), ref.var, None, TOL)
 
 
+def test_device_memory_storage_equals_the_host_storage(hip):
+    """sample_storage.DeviceMemory: levels handed over as torch CUDA tensors [M, n, 2] -- every estimate of an analysis equals,
+    bit for bit, the one over a host Memory storage with the same samples (scalar, tree and vector quantities; moments,
+    covariance, construct_density, estimate_domain)."""
+    import torch
+    from mlmc_amd import Legendre
+    from mlmc_amd.estimator import Estimate
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    from mlmc_amd.sample_storage import DeviceMemory
+    steps = [0.5, 0.07, 0.01]
+    levels = level_arrays([20011, 9000, 4001], steps, 4, 13)
+    host = _storage(levels, steps, _vec_spec())
+    dev = DeviceMemory()
+    dev.save_global_data(result_format=_vec_spec(), level_parameters=[[s] for s in steps])
+    for l, (f, c) in enumerate(levels):
+        pairs = np.stack([f, c if c is not None else np.zeros_like(f)], axis=-1)            # [M, n, 2]
+        dev.set_level_samples(l, torch.from_numpy(pairs).cuda())
+    torch.cuda.synchronize()
+    assert dev.get_n_collected() == host.get_n_collected() and dev.get_n_levels() == 3
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    out = []
+    for st in (host, dev):
+        qe.device_cache_clear()
+        root = make_root_quantity(st, _vec_spec())['q']
+        scalar = root[1]['0'][0, 0]
+        tree = (root[2]['0'][1, 0] - 0.25) * root[1]['0'][0, 0]
+        res = []
+        for q, fn in ((scalar, Legendre(12, dom)), (root, Legendre(5, dom)), (tree, Legendre(9, (-20.0, 20.0)))):
+            est = Estimate(q, st, fn)
+            res.append(est.estimate_moments() + est.estimate_covariance())
+        est = Estimate(scalar, st, Legendre(15, dom))
+        distr, _, r, _ = est.construct_density(tol=1e-8)
+        res.append((r.x, distr.density(np.linspace(dom[0], dom[1], 101))))
+        res.append((np.array(Estimate.estimate_domain(scalar, st)),))
+        out.append(res)
+    for a, b in zip(*out):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(NotImplementedError):
+        dev.save_samples({}, {})
+    qe.device_cache_clear()
+
+
 def test_device_chunk_cache(hip, monkeypatch):
     """Repeated estimates of the same quantity read the samples from HBM; appended samples and sub-sampled quantities
     bypass the cache."""
