@@ -109,9 +109,29 @@ class _DeviceChunkCache:
     def budget():
         return int(float(os.environ.get("MLMC_HIP_DEVICE_CACHE_GB", "64")) * 2 ** 30)
 
+    @staticmethod
+    def _owner_ref(owner):
+        """The cache must not keep a storage (and its host arrays) alive: entries hold a WEAK reference to their owner and
+        count only while it lives -- a dead owner's id may be recycled, a live one's cannot.  (Objects that cannot be weakly
+        referenced are held strongly, as before.)"""
+        if owner is None:
+            return None
+        import weakref
+        try:
+            return weakref.ref(owner)
+        except TypeError:
+            return lambda owner=owner: owner
+
+    @staticmethod
+    def _alive(item):
+        return item[3] is None or item[3]() is not None
+
     def get(self, key):
         with self._lock:
             item = self._items.get(key)
+            if item is not None and not self._alive(item):
+                self.drop(key)                                   # its storage is gone: the rows are garbage now
+                item = None
             if item is not None:
                 self._items.move_to_end(key)
                 self.hits += 1
@@ -119,14 +139,14 @@ class _DeviceChunkCache:
 
     def __contains__(self, key):
         with self._lock:
-            return key in self._items
+            item = self._items.get(key)
+            return item is not None and self._alive(item)
 
     def put(self, key, fine, coarse, owner=None):
         nbytes = fine.nbytes + (0 if coarse is None else coarse.nbytes)
         if nbytes > self.budget():
             return None
-        # `owner` (the source quantity) is kept alive with the entry, so its id() in the key cannot be re-used
-        item = (_upload(fine, count=False), None if coarse is None else _upload(coarse, count=False), nbytes, owner)
+        item = (_upload(fine, count=False), None if coarse is None else _upload(coarse, count=False), nbytes, self._owner_ref(owner))
         with self._lock:
             self._insert(key, item, nbytes)
             self.uploads += 1
@@ -135,7 +155,7 @@ class _DeviceChunkCache:
     def put_tensors(self, key, fine, coarse, owner=None):
         """Cache tensors that already live on the device (results of a lowered quantity, stored rows)."""
         nbytes = fine.numel() * 8 + (0 if coarse is None else coarse.numel() * 8)
-        item = (fine, coarse, nbytes, owner)
+        item = (fine, coarse, nbytes, self._owner_ref(owner))
         if nbytes > self.budget():
             return item
         with self._lock:
@@ -144,6 +164,9 @@ class _DeviceChunkCache:
 
     def _insert(self, key, item, nbytes):
         self.drop(key)                                   # a replaced entry gives its bytes back first
+        self._inserts = getattr(self, "_inserts", 0) + 1
+        if self._inserts % 64 == 0 or self._bytes + nbytes > self.budget():
+            self.drop_dead()                             # rows of storages that no longer exist
         while self._bytes + nbytes > self.budget() and self._items:
             _, (_, _, old, _) = self._items.popitem(last=False)
             self._bytes -= old
@@ -156,9 +179,14 @@ class _DeviceChunkCache:
             if item is not None:
                 self._bytes -= item[2]
 
+    def drop_dead(self):
+        with self._lock:
+            for key in [k for k, item in self._items.items() if not self._alive(item)]:
+                self.drop(key)
+
     def drop_owner(self, owner):
         with self._lock:
-            for key in [k for k, item in self._items.items() if item[3] is owner]:
+            for key in [k for k, item in self._items.items() if item[3] is not None and item[3]() is owner]:
                 self.drop(key)
 
     def clear(self):

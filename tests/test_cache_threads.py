@@ -124,3 +124,37 @@ def test_block_meta_forgets_dead_owners():
     meta.put(key, a, (2, 1, 10, 2))
     del a                                            # the owner dies: the weak reference goes dead with it
     assert meta.get(key, b, "gone") == "gone"
+
+
+def test_cache_entries_die_with_their_owner():
+    """The resident-sample cache holds its owners (storages, source quantities) weakly: rows of a storage that no longer
+    exists are invisible at once and are purged with the next insertions -- the cache must not keep a storage's host arrays
+    alive, and a recycled id() must not find another object's rows."""
+    import gc
+    from mlmc_amd.quantity import quantity_estimate as qe
+
+    class Storage:
+        pass
+
+    cache = qe._DeviceChunkCache()
+    a, b = Storage(), Storage()
+    ka, kb = ("row", id(a), 0), ("row", id(b), 0)
+    cache.put_tensors(ka, _FakeTensor(1000), None, owner=a)
+    cache.put_tensors(kb, _FakeTensor(500), _FakeTensor(500), owner=b)
+    assert ka in cache and kb in cache and cache._bytes == 8000 + 8000
+    del a
+    gc.collect()
+    assert ka not in cache and cache.get(ka) is None and kb in cache         # invisible at once, dropped by the failed lookup
+    assert cache._bytes == 8000
+    cache.drop_owner(b)
+    assert kb not in cache and cache._bytes == 0
+    # purge on insertion: dead entries give their bytes back without anybody looking them up
+    owners = [Storage() for _ in range(70)]
+    for i, o in enumerate(owners):
+        cache.put_tensors(("row", id(o), i), _FakeTensor(10), None, owner=o)
+    del owners, o
+    gc.collect()
+    keeper = Storage()
+    for i in range(64):
+        cache.put_tensors(("keep", id(keeper), i), _FakeTensor(1), None, owner=keeper)
+    assert all(k[0] == "keep" for k in cache._items) and cache._bytes == 64 * 8
