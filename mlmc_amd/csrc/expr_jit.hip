@@ -269,9 +269,17 @@ std::string generate(const std::vector<mlmc_expr_instr> &prog, int n_regs, int n
     return s;
 }
 
+// Process-wide cache of compiled forms, keyed by the program text.  Never destroyed (a leaked heap object): its entries unload
+// their code objects in their destructors, which must not run after the HIP runtime has shut down at process exit.
 std::map<std::string, std::shared_ptr<ExprJit>> &cache() {
-    static std::map<std::string, std::shared_ptr<ExprJit>> c;
-    return c;
+    static auto *c = new std::map<std::string, std::shared_ptr<ExprJit>>();
+    return *c;
+}
+// entries; beyond that, forms no live mlmc_expr refers to are dropped (MLMC_EXPR_JIT_CACHE_MAX overrides: tests)
+size_t jit_cache_max() {
+    const char *v = std::getenv("MLMC_EXPR_JIT_CACHE_MAX");
+    const long n = v ? std::atol(v) : 0;
+    return n > 0 ? (size_t)n : 512;
 }
 
 // evaluations of a program before it is compiled; -1: compiled forms are switched off (read at every call: tests flip it)
@@ -292,6 +300,12 @@ std::shared_ptr<ExprJit> expr_jit_lookup(const std::vector<mlmc_expr_instr> &pro
     auto &c = cache();
     auto it = c.find(key);
     if (it != c.end()) return it->second;
+    if (c.size() >= jit_cache_max()) {
+        // a long-running host that keeps building new trees: forget the forms only the cache still holds (their modules are
+        // unloaded by ~ExprJit; forms in use by a live handle stay -- the handle's shared_ptr keeps them alive either way)
+        for (auto jt = c.begin(); jt != c.end();)
+            jt = jt->second.use_count() == 1 ? c.erase(jt) : std::next(jt);
+    }
     auto e = std::make_shared<ExprJit>();
     e->prog = prog;
     e->n_regs = n_regs;

@@ -19,6 +19,12 @@ struct ExprJit {
     std::vector<char> code;
     hipModule_t module = nullptr;
     hipFunction_t fn_pair = nullptr, fn_single = nullptr;
+    ExprJit() = default;
+    ExprJit(const ExprJit &) = delete;
+    ExprJit &operator=(const ExprJit &) = delete;
+    ~ExprJit() {
+        if (module) (void)hipModuleUnload(module);      // runs under the API lock (handle destruction / cache trimming)
+    }
 };
 
 // Entry of the process-wide cache for this program (nullptr: compiled forms are switched off or the program is too long).

@@ -821,6 +821,35 @@ def test_compiled_program_with_more_than_64_stored_rows(hip, monkeypatch):
         results[n_rows] = plan
 
 
+def test_compiled_program_cache_is_bounded(hip, monkeypatch):
+    """The process-wide cache of compiled programs forgets the forms no live handle refers to once it is full (a long-running
+    host that keeps building new trees), unloading their code objects; forms in use survive and keep working."""
+    import torch
+    from mlmc_amd.quantity import lowering
+    monkeypatch.setenv("MLMC_EXPR_JIT", "1")
+    monkeypatch.setenv("MLMC_EXPR_JIT_AFTER", "0")
+    monkeypatch.setenv("MLMC_EXPR_JIT_CACHE_MAX", "4")
+    OP = lowering.OP
+    n = 3001
+    x = torch.randn(n, 2, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+
+    def plan_for_constant(c):
+        prog = [(OP["LOAD"], 0, 0, 0, 0.0), (OP["ADD"] | lowering.IMM_B, 1, 0, 0, float(c)), (OP["STORE"], 0, 1, 0, 0.0)]
+        return lowering.DevicePlan(None, [0], 1, prog, 2, False)
+    keeper = plan_for_constant(1000.0)
+    f, c, _ = keeper.evaluate([x], has_coarse=True, n=n, sync=True)
+    assert keeper.jit_state() == ("compiled", 1)
+    for k in range(12):                                   # twelve short-lived programs through a cache of four
+        p = plan_for_constant(float(k))
+        f, c, _ = p.evaluate([x], has_coarse=True, n=n, sync=True)
+        assert p.jit_state() == ("compiled", 1)
+        assert torch.equal(f[0], x[:, 0] + float(k)) and torch.equal(c[0], x[:, 1] + float(k))
+        del p
+    f, c, _ = keeper.evaluate([x], has_coarse=True, n=n, sync=True)           # its form was never dropped: a live handle holds it
+    assert keeper.jit_state() == ("compiled", 2) and torch.equal(f[0], x[:, 0] + 1000.0)
+
+
 def test_device_tree_special_values(hip):
     """np.remainder / maximum / minimum / sign / comparisons with NaN, infinities, zeros of both signs."""
     import torch
