@@ -1018,7 +1018,10 @@ def _estimate_mean(quantity, group, variance):
                 if subsample_params is not None and pair[0].shape[-1] > 0:   # the whole level is one resident chunk
                     pair = _subsample_on_device(pair, subsample_params[level_id])
                 push_pair(level_id, pair)
-    specs = [cs for cs in storage_q.chunks() if int(cs.level_id) not in level_done]
+    # (a storage that cuts its levels into hundreds of chunks: when every level is served level-wide from HBM the chunk
+    # specs need not even be generated)
+    all_levels = {int(l) for l in level_ids}
+    specs = [] if level_done >= all_levels else [cs for cs in storage_q.chunks() if int(cs.level_id) not in level_done]
     host_storage = plan is not None and not hasattr(getattr(plan.leaf, "_storage", None), "device_row")
     # Levels of a lowered tree that the storage hands out in several chunks of [n][2][M] records: the whole level becomes
     # ONE device tensor in the storage's layout -- resident from an earlier estimate of any quantity over this storage, or
