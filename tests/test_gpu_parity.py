@@ -481,6 +481,31 @@ def test_covariance_more_than_64_moments(hip, R):
         _check_against(n, n_rm, s, sp, ref)
 
 
+def test_covariance_of_130_moments_of_a_vector_quantity(hip):
+    """More than 128 moments (values path, 64 x 64 blocks) with two components sharing one mask: every component equals the
+    scalar estimate of its own samples when no sample is masked, and the shared mask drops a sample for both."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-3.7, 3.7)
+    R = 130
+    levels = level_arrays([700, 401], [0.3, 0.02], 2, 0)
+    clean = [(np.clip(f, -3.6, 3.6), None if c is None else np.clip(c, -3.6, 3.6)) for f, c in levels]
+    n, n_rm, s, sp = _run_accum(Legendre(R, dom), clean, mode=LevelAccumulator.COV, n_comp=2)
+    assert np.all(n_rm == 0)
+    for m in range(2):
+        one = [(f[m:m + 1], None if c is None else c[m:m + 1]) for f, c in clean]
+        n1, _, s1, sp1 = _run_accum(Legendre(R, dom), one, mode=LevelAccumulator.COV)
+        assert np.array_equal(n, n1)
+        blk = slice(m * R * R, (m + 1) * R * R)
+        assert np.array_equal(s[:, blk], s1) and np.array_equal(sp[:, blk], sp1)
+    masked = [(f.copy(), None if c is None else c.copy()) for f, c in clean]
+    masked[0][0][1, 5] = np.nan                     # component 1 of sample 5 at level 0
+    masked[1][1][0, 7] = 9.0                        # coarse value of component 0 outside the domain at level 1
+    n2, n_rm2, s2, _ = _run_accum(Legendre(R, dom), masked, mode=LevelAccumulator.COV, n_comp=2)
+    assert list(n_rm2) == [1, 1] and np.array_equal(n2, n - 1)
+    assert not np.array_equal(s2[:, :R * R], s[:, :R * R])           # the other component lost the sample too
+
+
 def test_rccl_allreduce_path_single_rank(hip):
     """The N > 1 exchange step (finalize into device buffers + torch.distributed all-reduce, backend nccl = RCCL) run
     with one rank in a child process: bench.py with MLMC_HIP_FORCE_DIST=1 must give the same estimate."""

@@ -212,3 +212,29 @@ def test_construct_density_is_one_device_pass_and_agrees_with_the_two_pass_chain
     monkeypatch.setenv("MLMC_HIP_LINEARIZE", "0")
     d4, _, res4, _ = Estimate(q, st, Legendre(21, DOM)).construct_density(tol=1e-8)
     assert np.max(np.abs(d3.density(x) - d4.density(x))) < 1e-7 and np.max(np.abs(d3.density(x) - d1.density(x))) > 1e-9
+
+
+@pytest.mark.gpu
+def test_linearised_covariance_mean_of_a_vector_quantity(monkeypatch):
+    """Four components, one mask for all (a sample is dropped when any component is masked), both row layouts
+    (cov_at_bottom True / False): the linearised pass against the matrix-core pass, and 100 moments (a 199-term pass of the
+    run-time-window kernels) for a two-component quantity."""
+    from mlmc_amd import Legendre
+    from mlmc_amd.quantity import quantity_estimate as qe
+    from mlmc_amd.quantity.quantity import make_root_quantity
+    _hip()
+    steps = [0.5, 0.07, 0.01]
+    levels = level_arrays([5001, 2500, 1200], steps, 4, 9)
+    st, spec = _storage(levels, steps, chunk_size=1500, M=4)
+    root = make_root_quantity(st, spec)['q'][1]['0']
+    for R, q in ((9, root), (70, root[:2])):
+        fn = Legendre(R, DOM)
+        for at_bottom in (True, False):
+            lin = qe.estimate_mean(qe.covariance(q, fn, cov_at_bottom=at_bottom), variance=False)
+            monkeypatch.setenv("MLMC_HIP_LINEARIZE", "0")
+            full = qe.estimate_mean(qe.covariance(q, fn, cov_at_bottom=at_bottom))
+            monkeypatch.delenv("MLMC_HIP_LINEARIZE")
+            assert np.array_equal(lin.n_samples, full.n_samples) and np.array_equal(lin.n_rm_samples, full.n_rm_samples)
+            assert lin.l_means.shape == full.l_means.shape and lin.mean.shape == full.mean.shape
+            rms = np.sqrt(np.maximum(full.l_vars, 0) + full.l_means ** 2)
+            assert np.all(np.abs(lin.l_means - full.l_means) <= 1e-10 * np.maximum(np.abs(full.l_means), rms) + 1e-300), (R, at_bottom)
