@@ -115,6 +115,19 @@ def test_mean_only_split_kernel_65_to_128_terms(R):
             assert np.all(np.isnan(sp1)) and not np.any(np.isnan(sp2))
             scale = np.sqrt(np.abs(sp2) * np.maximum(n2[:, None], 1)) + 1e-300
             assert np.all(np.abs(s1 - s2) <= 1e-12 * np.maximum(np.abs(s2), scale)), (R, N, cls.__name__)
+            if cls is Legendre and N[0] > 100 and R in (65, 127):
+                # two components sharing one mask (k_mask + the general, non-PLAIN loop of the split kernel)
+                lv2 = level_arrays(N, steps[:len(N)], 2, 13)
+                pair = []
+                for mean_only in (True, False):
+                    acc = LevelAccumulator(fn, len(N), LevelAccumulator.MOMENTS, n_comp=2, mean_only=mean_only)
+                    for l, (f, c) in enumerate(lv2):
+                        acc.push(l, f, c)
+                    pair.append(acc.finalize())
+                    acc.close()
+                assert np.array_equal(pair[0][0], pair[1][0]) and np.array_equal(pair[0][1], pair[1][1]) and np.all(np.isnan(pair[0][3]))
+                sc = np.sqrt(np.abs(pair[1][3]) * np.maximum(pair[1][0][:, None], 1)) + 1e-300
+                assert np.all(np.abs(pair[0][2] - pair[1][2]) <= 1e-12 * np.maximum(np.abs(pair[1][2]), sc))
             if cls is Legendre and N[0] > 100:
                 ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.moments_rows(onp.Basis(kind, R, DOM), x))
                 assert np.array_equal(n1, ref.n_samples) and np.array_equal(r1, ref.n_rm_samples)
