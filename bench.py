@@ -177,6 +177,7 @@ def timed_loop(step, acc, steps, warmup, preroll_ms, ctx):
             step()
         acc.kernel_time()                               # drop the warm-up launches from the totals
         acc.kernel_flops()
+        acc.aux_kernel_time()
         ctx.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -189,8 +190,9 @@ def timed_loop(step, acc, steps, warmup, preroll_ms, ctx):
     # read back once, after the clock has stopped
     kt = list(acc.kernel_time())
     mfma_flops = acc.kernel_flops()
+    aux = acc.aux_kernel_time()
     elapsed, k_ms = ctx.max_over_ranks([elapsed, kt[0]])
-    return elapsed, pre, res, [k_ms, int(kt[1]), int(kt[2]), int(mfma_flops)]
+    return elapsed, pre, res, [k_ms, int(kt[1]), int(kt[2]), int(mfma_flops), float(aux[0]), int(aux[1])]
 
 
 def alg_flops(mode, R, pairs, singles):
@@ -206,11 +208,15 @@ def roofline_block(mode, basis, R, pairs_per_step, singles_per_step, kt, steps, 
     kernel at R >= 12 (28 flop/B at R = 32 against a ridge of 9.8), fp64 MFMA for the covariance kernel; the HBM figures
     (algorithmic bytes / average launch duration) ride beside it under "hbm".
     Covariance: `achieved` / `frac` count the flops the matrix pipe EXECUTES -- 512 per 16 x 16 tile and sample, the tiles
-    of the symmetric Gram matrices once (SURVEY 8(d) allows symmetric halves; R = 64: 42 tiles per pair, 20 per level-0
-    sample), as reported by the library (mlmc_accum_kernel_flops) -- a physical fraction of the fp64 matrix peak.  The
+    of the symmetric Gram matrices once (SURVEY 8(d) allows symmetric halves), as reported by the library
+    (mlmc_accum_kernel_flops) -- a physical fraction of the fp64 matrix peak.  At 33..64 polynomial moments the matrix
+    cores compute the two Gram matrices of the VARIANCE only (R = 64: 16 + 10 = 26 tiles per pair, 10 per level-0 sample;
+    with the mean's Gram matrix it was 42 / 20): the mean of the covariance comes from one mean-only launch of the moments
+    kernel over 2 R - 1 terms (product linearisation, mlmc_hip.h), reported beside it under "aux_kernel".  The
     reference-form count (6 R^2 + 14 R per pair: every entry of three R x R matrices) rides beside it under
     "reference_form"; it exceeds what any kernel that uses the symmetry has to execute, so its fraction can pass 1."""
-    k_ms, launches, k_bytes, mfma_flops = kt
+    k_ms, launches, k_bytes, mfma_flops = kt[:4]
+    aux_ms, aux_launches = (kt[4], kt[5]) if len(kt) > 4 else (0.0, 0)
     per_step = max(launches // max(steps, 1), 1)
     avg_launch_ms = k_ms / max(launches, 1)
     gbs = (k_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
@@ -233,7 +239,20 @@ def roofline_block(mode, basis, R, pairs_per_step, singles_per_step, kt, steps, 
     kname, peak = "k_cov_accum", FP64_MFMA_PEAK_TFLOPS
     ex = mfma_flops / max(steps, 1)
     ex_tf = ex / step_kernel_s / 1e12 if step_kernel_s > 0 else 0.0
-    return dict(bound="mfma", achieved=round(ex_tf, 3), peak=peak, unit="TFLOP/s", frac=round(ex_tf / peak, 4),
+    aux = {}
+    if aux_launches:
+        # the covariance MEAN comes from the level sums of the 2 R - 1 moments of the product linearisation: one mean-only
+        # launch of the moments kernel per estimate beside the matrix-core launches (which then execute G1, G2 only)
+        K = 2 * R - 1
+        # flops per term: recurrence (multiply + FMA = 3) per value, difference 1, sum 1 -> 8 per pair, 4 per level-0 sample
+        aux_flops = (8 * K) * pairs_per_step + (4 * K) * singles_per_step
+        aux_s = aux_ms / 1e3 / max(steps, 1)
+        aux = {"aux_kernel": {"kernel": "k_moments_accum_split (mean-only, %d terms: product linearisation of the covariance mean)" % K,
+                              "ms_per_step": round(1e3 * aux_s, 4), "launches_per_step": aux_launches // max(steps, 1),
+                              "bound": "valu_f64", "achieved": round(aux_flops / aux_s / 1e12, 3) if aux_s > 0 else 0.0,
+                              "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(aux_flops / aux_s / 1e12 / FP64_VALU_PEAK_TFLOPS, 4) if aux_s > 0 else 0.0}}
+    return dict(**aux, bound="mfma", achieved=round(ex_tf, 3), peak=peak, unit="TFLOP/s", frac=round(ex_tf / peak, 4),
                 **pmc_traffic(config_key, kname), kernel=kname, executed_mfma_flops_per_step=int(ex),
                 reference_form={"alg_flops_reference_form": int(flops), "achieved": round(tflops, 3), "frac": round(tflops / peak, 4),
                                 "note": "6 R^2 + 14 R per pair (4 R^2 + 8 R at level 0), quantity_estimate.py:131-147: every entry of "

@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define MLMC_ABI_VERSION 4   /* 2: strides in mlmc_expr_eval, chaining flags, mlmc_accum_estimate_packed; 3: mlmc_wait_event;
-                              * 4: x_lo / x_hi in mlmc_basis_desc, mlmc_expr_state, mlmc_accum_kernel_flops */
+#define MLMC_ABI_VERSION 5   /* 2: strides in mlmc_expr_eval, chaining flags, mlmc_accum_estimate_packed; 3: mlmc_wait_event;
+                              * 4: x_lo / x_hi in mlmc_basis_desc, mlmc_expr_state, mlmc_accum_kernel_flops;
+                              * 5: mlmc_accum_aux_kernel_time */
 
 /* basis kinds -- mlmc/moments.py: Legendre :174-229, Monomial :111-130, Fourier :133-171;
  * IDENTITY = the quantity itself (estimate_mean of a plain quantity, quantity_estimate.py:22-80);
@@ -151,6 +152,16 @@ int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t
  * form count 6 R^2 per pair (quantity_estimate.py:131-147); it is the numerator of a physical matrix-pipe fraction.
  * Returns the total and clears it. */
 int mlmc_accum_kernel_flops(mlmc_accum *a, int64_t *mfma_flops);
+/* A MLMC_MODE_COV accumulator WITH variances of 33..64 plain Legendre or monomial moments splits its work: the matrix cores
+ * accumulate only the two Gram matrices of the VARIANCE (G1, G2: 26 instead of 42 tiles per pair at R = 64), and the MEAN
+ * (quantity_estimate.py:131-147 + :59-65: level sums of f_i f_j - c_i c_j) comes from the level sums of the 2 R - 1 moments
+ * of the same family through the product linearisation phi_i phi_j = sum_k c_ijk phi_k (Legendre: Adams' formula, non-negative
+ * coefficients that sum to one) -- one mean-only pass of the moments kernel over the same chunks with the same keep / drop
+ * decisions, contracted on the device at finalize.  Same outputs, same counts; the means agree with the direct sums to rounding
+ * (a convex combination of sums instead of sums of products).  MLMC_HIP_LINEARIZE=0 in the environment keeps all three Gram
+ * matrices on the matrix cores.  This call reports the HIP-event time, launches and algorithmic bytes of that auxiliary
+ * moments pass (zeros when the accumulator has none), like mlmc_accum_kernel_time does for the matrix-core launches. */
+int mlmc_accum_aux_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes);
 
 /* ---- maximum-entropy density (mlmc/tool/simple_distribution.py:9-327) ------------------ */
 typedef struct {

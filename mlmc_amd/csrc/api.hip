@@ -118,6 +118,50 @@ static void log_keep_interval(const BasisParams &p, double *x_lo, double *x_hi) 
     *x_hi = as_double(last);
 }
 
+// Product linearisation phi_i phi_j = sum_k c_ijk phi_k of the polynomial families, k < 2 R - 1 (mlmc_hip.h,
+// mlmc_accum_aux_kernel_time).  Legendre: Adams' formula with A(n) = (2n - 1)!! / n!,
+//   c_ijk = (2k + 1) / (2s + 1) * A(s - i) A(s - j) A(s - k) / A(s),  2s = i + j + k,  |i - j| <= k <= i + j,  i + j + k even,
+// walked along k by ratio recurrences in extended precision (every factor is O(1), no factorial is formed) and rounded once;
+// max / min of (i, j) enter, so the table is bit for bit symmetric.  Monomials: t^i t^j = t^(i + j).
+bool product_table(int kind, int R, std::vector<double> &out) {
+    if (kind != MLMC_LEGENDRE && kind != MLMC_MONOMIAL) return false;
+    const int K = 2 * R - 1;
+    const size_t RR = (size_t)R * R;
+    out.assign((size_t)K * RR, 0.0);
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < R; ++j) {
+            const size_t ij = (size_t)i * R + j;
+            if (kind == MLMC_MONOMIAL) { out[(size_t)(i + j) * RR + ij] = 1.0; continue; }
+            typedef long double ld;
+            const int hi = i > j ? i : j, lo = i > j ? j : i;
+            const ld diff = (ld)(hi - lo);
+            // first term k = |i - j| (s = hi):  (2 diff + 1) / (2 hi + 1) * A(diff) A(lo) / A(hi)
+            ld c = (2 * diff + 1) / (2 * (ld)hi + 1);
+            for (int t = 1; t <= lo; ++t) {
+                const ld tt = (ld)t;
+                c = c * ((2 * tt - 1) / tt * (diff + tt) / (2 * (diff + tt) - 1));
+            }
+            for (int t = 0; t <= lo; ++t) {          // term t: k = diff + 2 t, s = hi + t
+                const int k = (hi - lo) + 2 * t;
+                out[(size_t)k * RR + ij] = (double)c;
+                if (t == lo) break;
+                const ld s = (ld)hi + t, kk = (ld)k;
+                const ld si = s - hi, sj = s - lo, sk = s - kk;
+                ld ratio = ((2 * kk + 5) / (2 * s + 3)) / ((2 * kk + 1) / (2 * s + 1));
+                ratio = ratio * ((2 * si + 1) / (si + 1)) * ((2 * sj + 1) / (sj + 1));
+                ratio = ratio * (sk / (2 * sk - 1));          // A(sk - 1) / A(sk)
+                ratio = ratio * ((s + 1) / (2 * s + 1));      // A(s) / A(s + 1)
+                c = c * ratio;
+            }
+        }
+    return true;
+}
+
+static bool linearize_enabled() {
+    const char *e = std::getenv("MLMC_HIP_LINEARIZE");
+    return !(e && e[0] == '0');
+}
+
 static int need_runtime() {
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     return 0;
@@ -371,6 +415,34 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->d_out_nd = (double *)(a->d_out_n + 2 * (size_t)n_levels);
     a->d_out_s = a->d_out_nd + 2 * (size_t)n_levels;
     a->d_out_sp = a->d_out_s + (size_t)n_levels * a->K;
+    // covariance WITH variances of 33..64 plain polynomial moments: mean through the product linearisation (mlmc_hip.h)
+    if (mode == MLMC_MODE_COV && !mean_only && !a->cov_from_values && b->out_size == 0 && b->p.size > 32 && b->p.size <= 64 &&
+        (b->p.kind == MLMC_LEGENDRE || b->p.kind == MLMC_MONOMIAL) && linearize_enabled()) {
+        std::vector<double> table;
+        product_table(b->p.kind, a->R, table);
+        mlmc_basis_desc d;
+        std::memset(&d, 0, sizeof(d));
+        d.kind = b->p.kind;
+        d.size = 2 * a->R - 1;
+        d.shift = b->p.shift; d.scale = b->p.scale; d.ref0 = b->p.ref0; d.ref1 = b->p.ref1;
+        d.is_log = b->p.is_log; d.is_clip = b->p.is_clip;
+        d.x_lo = b->p.x_lo; d.x_hi = b->p.x_hi;              // the very thresholds of the caller's basis: the same samples are kept
+        int rc = mlmc_basis_create(&d, &a->lin_basis);
+        if (!rc) rc = mlmc_accum_create(a->lin_basis, n_levels, MLMC_MODE_MOMENTS | MLMC_MODE_MEAN_ONLY, n_comp, &a->lin);
+        if (!rc) {
+            a->lin_basis->p.x_lo = b->p.x_lo;                // (a desc with x_lo == x_hi == 0 would have been bisected anew)
+            a->lin_basis->p.x_hi = b->p.x_hi;
+            a->lin->host_outputs = false;                    // its totals are read on the device (launch_cov_finalize)
+            a->lin_K = d.size;
+            hipError_t e = hipMalloc(&a->d_lin_prod, sizeof(double) * table.size());
+            if (e == hipSuccess) e = hipMemcpy(a->d_lin_prod, table.data(), sizeof(double) * table.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = fail(std::string("mlmc_accum_create: ") + hipGetErrorString(e));
+        }
+        if (rc) {
+            mlmc_accum_destroy(a);
+            return rc;
+        }
+    }
     *out = a;
     return mlmc_accum_reset(a);
 }
@@ -383,6 +455,7 @@ int mlmc_accum_reset(mlmc_accum *a) {
     a->pending.clear();
     std::fill(a->level_flushed.begin(), a->level_flushed.end(), 0);
     MLMC_HIP_CHECK(hipMemsetAsync(a->d_state, 0, a->state_bytes, st));
+    if (a->lin) return mlmc_accum_reset(a->lin);
     return 0;
 }
 
@@ -390,6 +463,9 @@ void mlmc_accum_destroy(mlmc_accum *a) {
     MLMC_API_GUARD;
     if (!a) return;
     if (rt().ready) (void)wait_stream(rt().stream);
+    if (a->lin) mlmc_accum_destroy(a->lin);
+    if (a->lin_basis) mlmc_basis_destroy(a->lin_basis);
+    if (a->d_lin_prod) (void)hipFree(a->d_lin_prod);
     void *ptrs[] = {a->d_state, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c, a->d_mask, a->d_out, a->d_vals_f, a->d_vals_c};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -509,13 +585,20 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             }
         } else {
             // all components of a vector quantity in one launch (grid.y = component; they share the mask)
-            rc = m == 0 ? launch_cov_accum(a, level, 0, d_f, d_c, d_mask, n, count_in_kernel, a->mean_only ? 2 : 0, a->n_comp) : 0;
+            rc = m == 0 ? launch_cov_accum(a, level, 0, d_f, d_c, d_mask, n, count_in_kernel, a->mean_only ? 2 : (a->lin ? 3 : 0), a->n_comp) : 0;
+            // the extended moments of the linearised mean over the same chunk (same mask; the covariance kernel counts);
+            // device chunks wait for finalize and go out as ONE launch over all levels; staged host chunks and the components of a
+            // vector quantity (shared mask scratch) are launched when the push ends
+            if (!rc && a->lin)
+                rc = launch_moments_accum(a->lin, level, m, f_m, c_m, d_mask, n, false, mem_kind == MLMC_DEVICE || a->n_comp > 1);
         }
         if (rc) return rc;
     }
     // staged host data and the mask scratch are reused by the next push: their segments must be launched now
     if (a->mode == MLMC_MODE_MOMENTS && (mem_kind == MLMC_HOST || a->n_comp > 1))
         if (int rc = flush_moments(a)) return rc;
+    if (a->lin && (mem_kind == MLMC_HOST || a->n_comp > 1))
+        if (int rc = flush_moments(a->lin)) return rc;
     return 0;
 }
 
@@ -631,6 +714,16 @@ int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t
     a->ms_total = 0;
     a->launches = 0;
     a->alg_bytes = 0;
+    return 0;
+}
+
+int mlmc_accum_aux_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes) {
+    MLMC_API_GUARD;
+    if (!a) return fail("mlmc_accum_aux_kernel_time: null argument");
+    if (a->lin) return mlmc_accum_kernel_time(a->lin, ms, launches, alg_bytes);
+    if (ms) *ms = 0.0;
+    if (launches) *launches = 0;
+    if (alg_bytes) *alg_bytes = 0;
     return 0;
 }
 

@@ -125,6 +125,13 @@ struct mlmc_accum {
     int64_t launches = 0, alg_bytes = 0;
     int64_t mfma_flops = 0;   // executed matrix-core flops of the timed covariance launches (mlmc_accum_kernel_flops)
     int RP = 0;  // COV: R padded to 16
+    // COV with variances of 33..64 plain Legendre / monomial moments: the MEAN of the covariance comes from the level sums of
+    // the 2 R - 1 moments of the product linearisation (phi_i phi_j = sum_k c_ijk phi_k) -- an inner mean-only MOMENTS
+    // accumulator over the same chunks -- and the matrix cores compute G1, G2 only (26 instead of 42 tiles per pair)
+    mlmc_accum *lin = nullptr;
+    mlmc_basis *lin_basis = nullptr;      // the family's member of size lin_K = 2 R - 1
+    double *d_lin_prod = nullptr;         // [lin_K][R * R]: c_ijk, k-major
+    int lin_K = 0;
     std::vector<PendingSeg> pending;   // MOMENTS: chunks gathered into one launch (flushed by finalize / conflicts)
 };
 
@@ -141,6 +148,8 @@ int launch_moments_finalize(mlmc_accum *a);
 int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, const double *d_c, const uint8_t *d_mask,
                      int64_t n, bool count, int gram_mode, int ncomp = 1);
 int launch_cov_finalize(mlmc_accum *a);
+// c_ijk of the product linearisation, k-major [2 R - 1][R * R]; false: the family has none here
+bool product_table(int kind, int R, std::vector<double> &out);
 int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_vf, const double *d_vc, const uint8_t *d_mask,
                            int64_t n, bool count, int gram_mode = 0);
 int ensure(void **p, size_t *cap, size_t bytes);

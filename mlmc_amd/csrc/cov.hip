@@ -115,6 +115,11 @@ __device__ __forceinline__ int cov_t4_pos(int s) { return MLMC_COV_B128 ? ((s & 
 #define MLMC_COV_WIDE_BATCH 32      // pairs per batch of the two-window (off-diagonal) blocks: 70 KB of LDS, two workgroups per
                                     // CU (64 pairs, 135 KB, one per CU: +3 % with variances, +5 % mean-only at R = 128)
 #endif
+// Gram matrices a kernel MODE leaves in its partial rows
+__host__ __device__ constexpr int cov_ng(int mode) { return mode == 0 ? 3 : (mode == 3 ? 2 : 1); }
+#ifndef MLMC_COV_VAR_RANKS
+#define MLMC_COV_VAR_RANKS 1        // rotating matrix-phase priorities in the variance-only 64-term kernel (as with all three Grams)
+#endif
 __host__ __device__ constexpr int cov_batch(int T, bool wide, bool vals, bool pair = true) {
     return (T <= 2 && !wide && !vals) ? (pair ? 128 : 256) : ((wide && pair && !vals) ? MLMC_COV_WIDE_BATCH : 64);
 }
@@ -139,6 +144,8 @@ __device__ __forceinline__ void cov_spline_store(const TermGen<MLMC_SPLINE> &g, 
 
 // MODE 0: G0, G1, G2 (covariance mean + variance);  MODE 1: G = D^T D only (variance of transformed moments);
 // MODE 2: G0 = D^T S only (covariance mean without its variance, e.g. Estimate.construct_density)
+// MODE 3 (64-term kernel only): G1, G2 without G0 -- the variance of the covariance, its mean coming from the level sums of
+// the 2 R - 1 moments of the product linearisation (api.hip: lin accumulator)
 // BI, BJ (T = 4 only): the 64 x 64 output block (rows = terms [64 BI, 64 BI + 64), columns = terms [64 BJ, ...)) of
 // a covariance with more than 64 moments; off-diagonal blocks keep two term windows in LDS (one workgroup per CU).
 // VALS: `fine` / `coarse` hold already evaluated moment values [n][R] (row-major, NaN rows = masked samples) instead
@@ -456,7 +463,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     constexpr int NT = 64;
     constexpr int TA = 64 * BD;
     constexpr int N_EVAL = TA + NT;
-    constexpr bool BLK = PAIR && MODE == 0 && MLMC_COV_BLK22 && COV_T4_BATCH == 32;   // 2 x 2 tile blocks per wave
+    constexpr bool BLK = PAIR && (MODE == 0 || MODE == 3) && MLMC_COV_BLK22 && COV_T4_BATCH == 32;   // 2 x 2 tile blocks per wave
     constexpr bool BLK2 = PAIR && MODE == 2 && MLMC_COV_BLK22 && COV_T4_BATCH == 32;  // the same for the mean-only G0
     constexpr int ONE = BLK ? 2 : ((PAIR && MLMC_COV_T4_ONE_LIST && COV_T4_BATCH == 32) ? 1 : 0);   // kind of tile list
     constexpr int NS = xsym_n(ONE, W);
@@ -465,7 +472,8 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     // 1.88 -> 1.65 ms per 1e7 samples)
     constexpr int W1 = (MODE == 0 && !PAIR) ? (W + 2) % 4 : W;
     constexpr int NS1 = sym_n(W1);
-    constexpr int NFULL = (MODE == 0 && PAIR) ? 2 : ((MODE == 2 && PAIR) ? 1 : 0);     // G0 (and G1): full row W
+    constexpr int NFULL = (MODE == 0 && PAIR) ? 2 : (((MODE == 2 || MODE == 3) && PAIR) ? 1 : 0);     // G0 (and G1): full row W
+    constexpr int GV = MODE == 3 ? 0 : 1;          // accumulator set of G1
     constexpr int NSYMM = (MODE == 0 && !PAIR) ? 2 : 1;    // symmetric matrices handled through the tile list
     const int lane = threadIdx.x & 63;
 
@@ -517,7 +525,7 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
     // rank of the workgroup among the COV_T4_WGS that share its CU: the dispatcher deals the workgroups of a full grid
     // (launch_cov_accum: COV_T4_WGS per CU) round-robin over the CUs, so the partners of block b are b + n_cu, b + 2 n_cu, ...
     // (checked with HW_ID in tools/prof_cov.hip); all four waves of a workgroup share the rank
-    constexpr bool RANKS = MODE == 0 && PAIR;      // rotating priorities (see MLMC_COV_MFMA_PRIO)
+    constexpr bool RANKS = (MODE == 0 || (MODE == 3 && MLMC_COV_VAR_RANKS)) && PAIR;      // rotating priorities (see MLMC_COV_MFMA_PRIO)
     const unsigned per_round = gridDim.x >= (unsigned)COV_T4_WGS ? gridDim.x / (unsigned)COV_T4_WGS : 1u;
     const unsigned prio_slot = (blockIdx.x / per_round) % (unsigned)COV_T4_WGS;
     MLMC_COV_EVAL_PRIO(RANKS);
@@ -606,20 +614,21 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
                     const double dr2 = d[RA + r] * d[RA + r];
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        accf[0][2 * r + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[RA + r], sm[CA + c], accf[0][2 * r + c], 0, 0, 0);
-                        accf[1][2 * r + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(dr2, sm[CA + c] * sm[CA + c], accf[1][2 * r + c], 0, 0, 0);
+                        if (MODE == 0)
+                            accf[0][2 * r + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[RA + r], sm[CA + c], accf[0][2 * r + c], 0, 0, 0);
+                        accf[GV][2 * r + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(dr2, sm[CA + c] * sm[CA + c], accf[GV][2 * r + c], 0, 0, 0);
                     }
                 }
 #pragma unroll
                 for (int t = 0; t < NS; ++t)
                     accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ds[xsym_i(ONE, W, t)], ds[xsym_j(ONE, W, t)], accs[0][t], 0, 0, 0);
-            } else if (MODE == 0 && PAIR) {
+            } else if ((MODE == 0 || MODE == 3) && PAIR) {
                 const double dw2 = d[W] * d[W];
                 double ds[4];
 #pragma unroll
                 for (int J = 0; J < 4; ++J) {
-                    accf[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[W], sm[J], accf[0][J], 0, 0, 0);
-                    accf[1][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(dw2, sm[J] * sm[J], accf[1][J], 0, 0, 0);
+                    if (MODE == 0) accf[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[W], sm[J], accf[0][J], 0, 0, 0);
+                    accf[GV][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(dw2, sm[J] * sm[J], accf[GV][J], 0, 0, 0);
                     ds[J] = d[J] * sm[J];
                 }
 #pragma unroll
@@ -635,6 +644,13 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #pragma unroll
                 for (int t = 0; t < NS1; ++t)
                     accs[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[sym_i(W1, t)], f2[sym_j(W1, t)], accs[1][t], 0, 0, 0);
+            } else if (MODE == 3) {   // level 0, variance only: (F.F)^T (F.F), symmetric
+                double f2[4];
+#pragma unroll
+                for (int J = 0; J < 4; ++J) f2[J] = d[J] * d[J];
+#pragma unroll
+                for (int t = 0; t < NS; ++t)
+                    accs[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[xsym_i(ONE, W, t)], f2[xsym_j(ONE, W, t)], accs[0][t], 0, 0, 0);
             } else if (MODE == 2 && PAIR && BLK2) {   // covariance mean only: G0 = D^T S, a 2 x 2 block of tiles per wave
                 constexpr int RA = 2 * (W >> 1), CA = 2 * (W & 1);
 #pragma unroll
@@ -669,9 +685,18 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
 #endif
 
     // ---- partial tiles: one row per block, columns [g][row][col]; symmetric tiles are mirrored here ----
-    constexpr int NGOUT = (MODE == 0) ? 3 : 1;
+    constexpr int NGOUT = cov_ng(MODE);
     double *__restrict__ prow = partials + (int64_t)blockIdx.x * (NGOUT * NT * NT);
     const int r0 = lane >> 4, c0 = lane & 15;
+    if (MODE == 3 && PAIR) {        // [G1][G2]
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tr = BLK ? 2 * (W >> 1) + (J >> 1) : W, tc = BLK ? 2 * (W & 1) + (J & 1) : J;
+                prow[(16 * tr + r0 + 4 * r) * NT + 16 * tc + c0] = accf[0][J][r];
+            }
+    }
     if (MODE == 0 && PAIR) {
 #pragma unroll
         for (int J = 0; J < 4; ++J)
@@ -701,6 +726,14 @@ __device__ __forceinline__ void cov_t4_body(const BasisParams &bp,
             if (MODE == 0 && PAIR) {
                 prow[2 * NT * NT + row * NT + col] = accs[0][t][r];
                 if (xsym_i(ONE, W, t) != xsym_j(ONE, W, t)) prow[2 * NT * NT + col * NT + row] = accs[0][t][r];
+            } else if (MODE == 3) {   // pair levels: G2 = (D.S)^T (D.S) behind G1; level 0: G1 = G2 = (F.F)^T (F.F)
+                const bool off = xsym_i(ONE, W, t) != xsym_j(ONE, W, t);
+                prow[NT * NT + row * NT + col] = accs[0][t][r];
+                if (off) prow[NT * NT + col * NT + row] = accs[0][t][r];
+                if (!PAIR) {
+                    prow[row * NT + col] = accs[0][t][r];
+                    if (off) prow[col * NT + row] = accs[0][t][r];
+                }
             } else if (MODE == 0) {   // level 0: G0 = F^T F (G1 = G2 below)
                 prow[0 * NT * NT + row * NT + col] = accs[0][t][r];
                 if (xsym_i(ONE, W, t) != xsym_j(ONE, W, t)) prow[0 * NT * NT + col * NT + row] = accs[0][t][r];
@@ -744,7 +777,7 @@ __global__ __launch_bounds__(256, COV_T4_WGS) void k_cov_accum_t4(BasisParams bp
     // blockIdx.y = component of a vector quantity (see k_cov_accum): one partial row [3 or 1][64][64] per workgroup
     fine += (int64_t)blockIdx.y * n;
     if (PAIR) coarse += (int64_t)blockIdx.y * n;
-    partials += (int64_t)blockIdx.y * gridDim.x * (((MODE == 0) ? 3 : 1) * 64 * 64);
+    partials += (int64_t)blockIdx.y * gridDim.x * (cov_ng(MODE) * 64 * 64);
     if (blockIdx.y) pcounts = nullptr;
     // every wave runs its own specialisation (same barrier count in all of them); readfirstlane makes the wave index a scalar,
     // so this is a scalar branch -- as a per-lane switch the compiler predicates the four bodies with exec masks, and a
@@ -804,13 +837,12 @@ static int launch_cov_t(const BasisParams &bp, bool pair, int blocks, int ncomp,
             hipLaunchKernelGGL((k_cov_accum_t4<KIND, true, MODE, BI>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
         else
             hipLaunchKernelGGL((k_cov_accum_t4<KIND, false, MODE, BI>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts);
-        MLMC_HIP_CHECK(hipGetLastError());
-        return 0;
+    } else {            // (in the else branch: the generic kernel is not instantiated for the combinations above)
+        if (pair)
+            hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE, BI, BJ>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts, 0, 0);
+        else
+            hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE, BI, BJ>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts, 0, 0);
     }
-    if (pair)
-        hipLaunchKernelGGL((k_cov_accum<KIND, T, true, MODE, BI, BJ>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts, 0, 0);
-    else
-        hipLaunchKernelGGL((k_cov_accum<KIND, T, false, MODE, BI, BJ>), dim3(blocks, ncomp), dim3(256), 0, st, bp, d_f, d_c, d_mask, n, R, partials, pcounts, 0, 0);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1064,12 +1096,14 @@ static int launch_spline_band(mlmc_accum *a, int level, int comp, const double *
 }
 
 // 16 x 16 output tiles one sample (pair) contributes to in one block launch -- the kernels' tile lists above:
-// gram_mode 0 = G0, G1, G2 (level 0: two symmetric matrices), 1 = D^T D (symmetric), 2 = G0 only (level 0: F^T F, symmetric).
+// gram_mode 0 = G0, G1, G2 (level 0: two symmetric matrices), 1 = D^T D (symmetric), 2 = G0 only (level 0: F^T F, symmetric),
+// 3 = G1, G2 (level 0: one symmetric matrix).
 // x 512 = executed matrix-core flops per sample (mlmc_accum_kernel_flops).
 static int cov_tiles_per_sample(int T, bool diagonal, bool pair, int gram_mode) {
     const int full = T * T, upper = T * (T + 1) / 2;
     if (!diagonal) return (gram_mode == 0 ? (pair ? 3 : 2) : 1) * full;      // two term windows: no symmetry inside the block
     if (gram_mode == 0) return pair ? 2 * full + upper : 2 * upper;
+    if (gram_mode == 3) return pair ? full + upper : upper;
     if (gram_mode == 1 || !pair) return upper;
     return full;
 }
@@ -1086,14 +1120,16 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     hipStream_t st = rt().stream;
     const int T = (R <= 16) ? 1 : (R <= 32 ? 2 : 4);
     const int NT = 16 * T, NSL = 4 / T;
-    const int NG = gram_mode == 0 ? 3 : 1;
+    const int NG = cov_ng(gram_mode);
     const int NB = (R + 63) / 64;          // 64 x 64 output blocks per dimension
+    if (gram_mode == 3 && !(T == 4 && NB == 1)) return fail("covariance: the variance-only pass exists for 33..64 moments");
     const bool pair = d_c != nullptr;
     const int64_t bsz = T == 4 ? (pair ? COV_T4_BATCH : 2 * COV_T4_BATCH) : cov_batch(T, false, false, pair);
     const int64_t n_batches = (n + bsz - 1) / bsz;
     const size_t width = (size_t)NG * NT * NT;
     const BasisParams &bp = a->basis->p;
-    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0);
+    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0) +
+                     (gram_mode == 3 ? (int64_t)a->RP * a->RP : 0);      // variance only: the partial rows hold [G1][G2]
     for (int bi = 0; bi < NB; ++bi)
         for (int bj = 0; bj < NB; ++bj) {
             if (!pair && bj < bi) continue;   // level 0: symmetric matrices, block (bj, bi) is mirrored by the reduction
@@ -1112,7 +1148,8 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
             if (timed) if (int rc = timing_begin(a)) return rc;
             int rc;
 #define MLMC_COV_DISPATCH(KIND)                                                                                               \
-    rc = gram_mode == 2 ? launch_cov_kind<KIND, 2>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
+    rc = gram_mode == 3 ? launch_cov_t<KIND, 4, 3, 0, 0>(bp, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc)      \
+       : gram_mode == 2 ? launch_cov_kind<KIND, 2>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
        : diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
                         : launch_cov_kind<KIND, 0>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc)
             switch (bp.kind) {
@@ -1167,7 +1204,26 @@ __global__ void k_cov_finalize(const double *__restrict__ totals, const double *
                                                   : 0.25 * (cc * cc) * ((G1[i * RP + j] + G1[j * RP + i]) + 2.0 * G2[i * RP + j]);
 }
 
+// Mean of the covariance through the product linearisation: out_s[lc][i][j] = sum_k c_ijk (scale_k S_k[lc]), S = level sums of
+// the 2 R - 1 (scaled) moments of the inner accumulator.  The table is k-major: consecutive threads read consecutive entries.
+__global__ void k_cov_lin_mean(const double *__restrict__ prod, const double *__restrict__ lin_totals, const double *__restrict__ lin_scale,
+                               int R, int K, int64_t lin_width, double *__restrict__ out_s) {
+    extern __shared__ double m_s[];     // [K] true-value sums of this (level, component)
+    const int lc = blockIdx.y;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) m_s[k] = lin_scale[k] * lin_totals[(int64_t)lc * lin_width + k];
+    __syncthreads();
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int RR = R * R;
+    if (idx >= RR) return;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) acc = __builtin_fma(prod[(int64_t)k * RR + idx], m_s[k], acc);
+    out_s[(int64_t)lc * RR + idx] = acc;
+}
+
 int launch_cov_finalize(mlmc_accum *a) {
+    if (a->lin) {
+        if (int rc = flush_moments(a->lin)) return rc;
+    }
     const int n_lc = a->n_levels * a->n_comp;
     const bool vals = a->cov_from_values;              // TransformedMoments / more than 128 moments: accumulated from true values
     const int R = vals ? a->Rout : a->R;
@@ -1176,6 +1232,11 @@ int launch_cov_finalize(mlmc_accum *a) {
                        a->RP, a->int_width, a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n, a->d_out_nd,
                        a->mean_only ? 1 : 0);
     MLMC_HIP_CHECK(hipGetLastError());
+    if (a->lin) {       // G0 was not accumulated (gram_mode 3): the means come from the extended moments
+        hipLaunchKernelGGL(k_cov_lin_mean, dim3((R * R + 255) / 256, n_lc), dim3(256), sizeof(double) * a->lin_K, rt().stream,
+                           a->d_lin_prod, a->lin->d_totals, a->lin_basis->d_scale, R, a->lin_K, a->lin->int_width, a->d_out_s);
+        MLMC_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 

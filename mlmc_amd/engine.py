@@ -178,6 +178,15 @@ class LevelAccumulator:
         _lib.check(_lib.lib().mlmc_accum_kernel_time(self._h, C.byref(ms), C.byref(launches), C.byref(nbytes)))
         return ms.value, launches.value, nbytes.value
 
+    def aux_kernel_time(self):
+        """(ms, launches, algorithmic bytes) of the auxiliary moments pass of a covariance accumulator whose means come from
+        the product linearisation (`mlmc_accum_aux_kernel_time`; zeros when there is none); returns and clears the totals."""
+        ms = C.c_double()
+        launches = C.c_int64()
+        nbytes = C.c_int64()
+        _lib.check(_lib.lib().mlmc_accum_aux_kernel_time(self._h, C.byref(ms), C.byref(launches), C.byref(nbytes)))
+        return ms.value, launches.value, nbytes.value
+
     def kernel_flops(self):
         """Matrix-core flops the timed covariance launches executed since create or the previous call (symmetric Gram tiles
         counted once: `mlmc_accum_kernel_flops`); returns and clears the total."""

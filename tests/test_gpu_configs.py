@@ -221,7 +221,10 @@ def test_bench_multi_rank_default_is_config3_sharded(hip):
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1.0
     assert d["roofline"]["frac"] < d["roofline"]["reference_form"]["frac"]
     n_loc = d["config"]["samples_per_level_per_gpu"]
-    assert d["roofline"]["executed_mfma_flops_per_step"] == 512 * (42 * 4 + 20) * n_loc
+    # variance Grams only (16 + 10 tiles per pair, 10 per level-0 sample); the mean's Gram matrix is replaced by the aux pass
+    assert d["roofline"]["executed_mfma_flops_per_step"] == 512 * (26 * 4 + 10) * n_loc
+    aux = d["roofline"]["aux_kernel"]
+    assert aux["launches_per_step"] == 1 and aux["ms_per_step"] > 0 and "127 terms" in aux["kernel"]
     assert d["roofline"]["reference_form"]["alg_flops_reference_form"] == (6 * 64 * 64 + 14 * 64) * 4 * n_loc + (4 * 64 * 64 + 8 * 64) * n_loc
     assert "traffic_from_profile" in d["roofline"] and (d["roofline"]["traffic"] is None or d["roofline"]["traffic_profile_matches_build"])
     rc = d["result_check"]

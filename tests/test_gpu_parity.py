@@ -1136,3 +1136,74 @@ def test_adaptive_sampling_loop_matches_reference_trajectory(hip):
         assert done
         means, vars_ = est.estimate_moments(fn)
         assert np.allclose(means, case["means"], rtol=0, atol=1e-10) and np.allclose(vars_, case["vars"], rtol=1e-9, atol=1e-16)
+
+
+@pytest.mark.parametrize("R", [33, 40, 64])
+def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
+    """Covariance WITH variances of 33..64 plain polynomial moments: the matrix cores accumulate the variance Grams only, the
+    means come from the level sums of the 2 R - 1 moments of the family (mlmc_hip.h, mlmc_accum_aux_kernel_time).  Against the
+    oracle, and against the same library with all three Gram matrices on the matrix cores (MLMC_HIP_LINEARIZE=0): identical
+    counts, bit-identical second-moment sums, means equal to rounding; host chunks, several chunks per level, a two-component
+    quantity with its shared mask, and log=True moments."""
+    import torch
+    from mlmc_amd import Legendre, Monomial
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    levels = level_arrays([5301, 2500, 1777], [0.5, 0.07, 0.01], 1, 19)
+
+    def both(fn, lv, n_comp=1, device=False, split=False):
+        out = []
+        for lin in ("1", "0"):
+            monkeypatch.setenv("MLMC_HIP_LINEARIZE", lin)
+            acc = LevelAccumulator(fn, len(lv), LevelAccumulator.COV, n_comp=n_comp)
+            keep = []
+            for l, (f, c) in enumerate(lv):
+                parts = [(0, f.shape[-1])] if not split else [(0, f.shape[-1] // 3), (f.shape[-1] // 3, f.shape[-1])]
+                for lo, hi in parts:
+                    fa = np.ascontiguousarray(f[:, lo:hi] if n_comp > 1 else f[0, lo:hi])
+                    ca = None if c is None else np.ascontiguousarray(c[:, lo:hi] if n_comp > 1 else c[0, lo:hi])
+                    if device:
+                        fa = torch.from_numpy(fa).cuda()
+                        ca = None if ca is None else torch.from_numpy(ca).cuda()
+                        keep.append((fa, ca))
+                    acc.push(l, fa, ca)
+            out.append(acc.finalize())
+            aux = acc.aux_kernel_time()
+            acc.close()
+        monkeypatch.delenv("MLMC_HIP_LINEARIZE")
+        (n, n_rm, s, sp), (n0, n_rm0, s0, sp0) = out
+        assert np.array_equal(n, n0) and np.array_equal(n_rm, n_rm0)
+        assert np.array_equal(sp, sp0)                                    # the same instructions in the same order
+        scale = np.sqrt(np.abs(sp0) * n[:, None]) + 1e-300
+        assert np.max(np.abs(s - s0) / scale) < 1e-12, np.max(np.abs(s - s0) / scale)
+        return n, n_rm, s, sp
+
+    for cls, kind in ((Legendre, onp.LEGENDRE), (Monomial, onp.MONOMIAL)):
+        b = onp.Basis(kind, R, dom)
+        ref = onp.estimate_mean(to_chunks(levels), lambda x: onp.covariance_rows(b, x))
+        for device, split in ((False, False), (True, False), (True, True), (False, True)):
+            n, n_rm, s, sp = both(cls(R, dom), levels, device=device, split=split)
+            mean, var = _check_against(n, n_rm, s, sp, ref)
+            cov = mean.reshape(R, R)
+            assert np.array_equal(cov, cov.T)
+            S = s.reshape(len(levels), R, R)
+            assert S[0, 0, 0] == float(n[0]) and not S[1:, 0, 0].any()
+    # two components: a sample is dropped when any component is masked
+    lv2 = level_arrays([2800, 1100], [0.3, 0.02], 2, 6)
+    b = onp.Basis(onp.LEGENDRE, R, dom)
+    ref = onp.estimate_mean(to_chunks(lv2), lambda v: onp.covariance_rows(b, v))
+    for device in (False, True):
+        n, n_rm, s, sp = both(Legendre(R, dom), lv2, n_comp=2, device=device)
+        _check_against(n, n_rm, s, sp, ref)
+    # log=True: the keep / drop decision is the raw-value interval of the caller's basis, for both accumulators
+    rng = np.random.default_rng(5)
+    x = rng.lognormal(mean=0.3, sigma=0.8, size=9011)
+    f1 = x * (1 + 0.01 * rng.normal(size=x.size))
+    c1 = x * (1 + 0.03 * rng.normal(size=x.size))
+    f1[::501] = -1.0
+    lvl = [(x[None], None), (f1[None], c1[None])]
+    ldom = (0.05, 30.0)
+    bl = onp.Basis(onp.LEGENDRE, R, ldom, log=True)
+    ref = onp.estimate_mean(to_chunks(lvl), lambda v: onp.covariance_rows(bl, v))
+    n, n_rm, s, sp = both(Legendre(R, ldom, log=True), lvl)
+    _check_against(n, n_rm, s, sp, ref)

@@ -51,6 +51,7 @@ for case in os.environ["KB_CASES"].split(","):
         acc.estimate(chunks, reduce=False)
     acc.kernel_time()
     acc.kernel_flops()
+    acc.aux_kernel_time()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(reps):
@@ -58,7 +59,8 @@ for case in os.environ["KB_CASES"].split(","):
     wall = (time.perf_counter() - t0) / reps
     ms, launches, nb = acc.kernel_time()
     fl = acc.kernel_flops()
-    print("RES %%s %%.5f %%.5f %%d %%.4f" %% (case, ms / reps, 1e3 * wall, launches // reps, fl / reps / (ms / reps * 1e-3) / 1e12 if ms else 0.0), flush=True)
+    aux = acc.aux_kernel_time()[0]
+    print("RES %%s %%.5f %%.5f %%d %%.4f %%.5f" %% (case, ms / reps, 1e3 * wall, launches // reps, fl / reps / (ms / reps * 1e-3) / 1e12 if ms else 0.0, aux / reps), flush=True)
     acc.close()
 ''' % ROOT
 
@@ -89,16 +91,16 @@ def main():
                 continue
             for line in out.stdout.splitlines():
                 if line.startswith("RES "):
-                    _, case, k_ms, w_ms, launches, tf = line.split()
-                    res[name].setdefault(case, []).append((float(k_ms), float(w_ms), int(launches), float(tf)))
+                    _, case, k_ms, w_ms, launches, tf, aux = line.split()
+                    res[name].setdefault(case, []).append((float(k_ms), float(w_ms), int(launches), float(tf), float(aux)))
             print("round", rnd, name, "done", flush=True)
-    print("%-24s %-10s %12s %12s %9s %12s" % ("case", "lib", "kernel ms", "wall ms", "launches", "MFMA TF/s"))
+    print("%-24s %-10s %12s %12s %9s %12s %10s" % ("case", "lib", "kernel ms", "wall ms", "launches", "MFMA TF/s", "aux ms"))
     for case in args.cases:
         for name in libs:
             v = res[name].get(case)
             if v:
                 best = min(v)
-                print("%-24s %-10s %12.4f %12.4f %9d %12.2f" % (case, name, best[0], min(x[1] for x in v), best[2], max(x[3] for x in v)))
+                print("%-24s %-10s %12.4f %12.4f %9d %12.2f %10.4f" % (case, name, best[0], min(x[1] for x in v), best[2], max(x[3] for x in v), best[4]))
 
 
 if __name__ == "__main__":
