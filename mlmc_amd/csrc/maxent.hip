@@ -233,14 +233,18 @@ __global__ void k_me_scale_cols(double *__restrict__ Phi, const double *__restri
 
 
 // ------------------------------------------------------------------------------------------
-// The damped Newton iteration as ONE cooperative launch (SimpleDistribution's functional, no penalties).
+// The damped Newton iteration as ONE cooperative launch (SimpleDistribution's functional; with the end-point decay and
+// stabilisation penalties of the older Distribution solver when the options carry them).
 // The kernel-per-step formulation above pays launch latency and one host round trip per Newton step and per
 // line-search trial (~160 us per step); the problem itself is tiny.  Here NB workgroups each own a slice of QS
 // quadrature points: the slice of the scaled basis sits in LDS for the whole solve, every workgroup computes its
 // partial integral / gradient / Hessian from LDS, the partials are summed in a fixed order after a grid barrier, and
 // EVERY workgroup then runs the same Cholesky solve and takes the same decisions (regularisation, Armijo backtracking
 // -- four step lengths per barrier -- and convergence), so nothing has to be broadcast.  Same algorithm and constants
-// as the host loop of mlmc_maxent_solve, which stays as the path for the penalised functional and as fallback.
+// as the host loop of mlmc_maxent_solve, which stays as the fallback (and as the validation path: MLMC_MAXENT_STEPWISE=1).
+// With penalties the reference's gradient is not the gradient of its functional (distribution.py:375-380 scales the decay
+// term by |fun|), so -- as in the host loop -- a step is accepted when it lowers the gradient NORM: the trial point's
+// gradient needs the full partial sums anyway, and an accepted trial's sums are the next iterate's, whatever the step length.
 // The grid barrier spins on an agent-scope generation counter with a bounded number of polls: if the workgroups are
 // ever not co-resident the kernel gives up (result[5] = 1) instead of hanging, and the host falls back.
 // ------------------------------------------------------------------------------------------
@@ -262,6 +266,11 @@ struct CoopArgs {
     unsigned *bar;           // [2]: arrival counter (monotonic), generation
     int Q, R1, NB, QS, max_it;
     double tol;
+    // penalised functional (distribution.py:354-359, :375-380, :404-412); use_pen == 0: none of these is read
+    const double *end_diff;  // [2][R1] end-point derivative estimates / sigma
+    const double *prev;      // [n_prev] multipliers of the previous stage
+    int n_prev, use_pen;
+    double stab, coef;
 };
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {   // lane must be wave-uniform
@@ -307,7 +316,9 @@ __global__ __launch_bounds__(COOP_THREADS) void k_me_coop(CoopArgs A) {
     double *red = wsl + QS;                            // [16]
     double *mus = red + 16;                            // [R1] mu_i / sigma_i
     double *lsum = mus + R1;                           // [4][COOP_MAX_BLOCKS] line-search partials of all workgroups
-    double *Lm = lsum + 4 * COOP_MAX_BLOCKS;           // [R1][ld] Cholesky matrix; aliased by psi [QS][R1p] in phase A
+    double *endd = lsum + 4 * COOP_MAX_BLOCKS;         // [2][R1] end-point derivative rows (penalised functional)
+    double *prv = endd + 2 * R1;                       // [R1] previous stage's multipliers, zero beyond n_prev
+    double *Lm = prv + R1;                             // [R1][ld] Cholesky matrix; aliased by psi [QS][R1p] in phase A
     double *psi = Lm;
     __shared__ int abort_s, bad_s;
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -320,7 +331,29 @@ __global__ __launch_bounds__(COOP_THREADS) void k_me_coop(CoopArgs A) {
     }
     for (int q = tid; q < QS; q += COOP_THREADS) wsl[q] = q < nq ? A.w[q0 + q] : 0.0;
     for (int i = tid; i < R1; i += COOP_THREADS) { lam[i] = A.lam[i]; pdir[i] = 0.0; mus[i] = A.mu_s[i]; }
+    const bool pen = A.use_pen != 0;
+    const int n_prev = A.n_prev;
+    if (pen) {
+        for (int i = tid; i < 2 * R1; i += COOP_THREADS) endd[i] = A.end_diff[i];
+        for (int i = tid; i < R1; i += COOP_THREADS) prv[i] = i < n_prev ? A.prev[i] : 0.0;
+    }
     __syncthreads();
+    // penalty scalars at the point `pt`: red[8] = e_left . pt, red[9] = e_right . pt, red[11] = sum_{k < n_prev} (prev_k - pt_k)^2
+    auto pen_scalars = [&](const double *pt) {
+        if (tid < 64) {
+            double e0 = 0.0, e1 = 0.0, sq = 0.0;
+            for (int k = tid; k < R1; k += 64) {
+                e0 = __builtin_fma(endd[k], pt[k], e0);
+                e1 = __builtin_fma(endd[R1 + k], pt[k], e1);
+                if (k < n_prev) sq = __builtin_fma(prv[k] - pt[k], prv[k] - pt[k], sq);
+            }
+            e0 = wave_sum(e0);
+            e1 = wave_sum(e1);
+            sq = wave_sum(sq);
+            if (tid == 0) { red[8] = e0; red[9] = e1; red[11] = sq; }
+        }
+        __syncthreads();
+    };
 
     // rho w of the slice for up to 4 step lengths alpha_k = alpha0 / 2^k along pdir; 8 lanes share one (point, k)
     auto slice_density = [&](double alpha0, int n_alpha) {
@@ -343,13 +376,15 @@ __global__ __launch_bounds__(COOP_THREADS) void k_me_coop(CoopArgs A) {
     // (the usual case near the solution) they ARE the next iterate's integral / gradient / Hessian, so an accepted
     // step costs no line-search round trip at all; otherwise the step lengths 1/2, 1/4, ... are tried four per barrier.
     bool spec = false;
+    double alpha_try = 1.0, pen_ed0 = 0.0, pen_ed1 = 0.0, pen_fun_h = 0.0;     // penalised: step length of the trial point
+    int ls_count = 0;
     for (int it = 0; it <= A.max_it && ok;) {
 #ifdef MLMC_PROF_COOP
         unsigned long long st_[8];
         st_[0] = __builtin_amdgcn_s_memrealtime();
 #endif
         // ---- phase A: partial integral, gradient and Hessian of this slice at lam (or at lam + pdir) ----
-        slice_density(spec ? 1.0 : 0.0, 1);
+        slice_density(spec ? alpha_try : 0.0, 1);
         for (int idx = tid; idx < QS * R1; idx += COOP_THREADS) {
             const int q = idx / R1, i = idx % R1;
             psi[q * R1p + i] = ph[q * R1p + i] * rw[q];
@@ -400,7 +435,42 @@ __global__ __launch_bounds__(COOP_THREADS) void k_me_coop(CoopArgs A) {
 #ifdef MLMC_PROF_COOP
         st_[4] = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (spec) {
+        if (spec && pen) {
+            // the totals belong to trial = lam + alpha_try pdir: its gradient (with penalties) decides (same in every workgroup)
+            for (int i = tid; i < R1; i += COOP_THREADS) trial[i] = __builtin_fma(alpha_try, pdir[i], lam[i]);
+            __syncthreads();
+            pen_scalars(trial);
+            double lin_t = 0.0;
+            for (int k = 0; k < R1; ++k) lin_t = __builtin_fma(mus[k], trial[k], lin_t);
+            const double p0 = fmax(red[8], 0.0), p1 = fmax(red[9], 0.0);
+            const double fun_g = lin_t + A.tot[npairs] * A.sigma[0];                          // distribution.py:376
+            if (tid < 64) {
+                double a = 0.0;
+                for (int i = tid; i < R1; i += 64) {
+                    double gi = (mus[i] - A.tot[npairs + i]) + fabs(fun_g) * A.coef * 2.0 * (p0 * endd[i] + p1 * endd[R1 + i]);
+                    if (i < n_prev) gi += A.stab * (trial[i] - prv[i]);
+                    a = __builtin_fma(gi, gi, a);
+                }
+                a = wave_sum(a);
+                if (tid == 0) red[13] = sqrt(a);
+            }
+            __syncthreads();
+            const double gt = red[13];
+            if (!(gt == gt && gt < gnorm)) {
+                alpha_try *= 0.5;
+                if (++ls_count < 40) continue;                               // the next round evaluates the shorter step
+                spec = false;
+                tau = (tau == 0.0) ? 1e-8 * (1.0 + fabs(F)) : tau * 100.0;
+                if (tau > 1e20) break;
+                continue;                                                   // re-evaluate at lam with the larger shift
+            }
+            for (int i = tid; i < R1; i += COOP_THREADS) lam[i] = trial[i];
+            __syncthreads();
+            tau = (alpha_try == 1.0) ? tau * 0.1 : tau;
+            if (tau < 1e-14) tau = 0.0;
+            ++nit;
+            spec = false;                                                   // the totals ARE those of the new lam: on to phase C
+        } else if (spec) {
             // the totals belong to lam + pdir: Armijo test of the full step (same in every workgroup)
             spec = false;
             const double lin0 = F - red[4];                                 // mu~ . lam  (red[4]: integral at lam)
@@ -463,6 +533,30 @@ __global__ __launch_bounds__(COOP_THREADS) void k_me_coop(CoopArgs A) {
             for (int k = 0; k < R1; ++k) lin = __builtin_fma(mus[k], lam[k], lin);
             F = lin + A.tot[npairs + R1];
             moment0 = A.tot[npairs] * A.sigma[0];
+            if (pen) {      // k_me_penalty's formulas at lam, applied by every workgroup to its own copy
+                pen_scalars(lam);
+                pen_ed0 = red[8];
+                pen_ed1 = red[9];
+                const double p0 = fmax(pen_ed0, 0.0), p1 = fmax(pen_ed1, 0.0);
+                const double fun_g = lin + moment0;                                             // distribution.py:376
+                pen_fun_h = lin + A.tot[0] * A.sigma[0] * A.sigma[0];                           // distribution.py:401-402
+                for (int i = tid; i < R1; i += COOP_THREADS) {
+                    double gi = g[i] + fabs(fun_g) * A.coef * 2.0 * (p0 * endd[i] + p1 * endd[R1 + i]);
+                    if (i < n_prev) gi += A.stab * (lam[i] - prv[i]);
+                    g[i] = gi;
+                }
+                for (int idx = tid; idx < R1 * R1; idx += COOP_THREADS) {
+                    const int i = idx / R1, j = idx % R1;
+                    double h = 0.0;
+                    if (pen_ed0 > 0) h += fabs(pen_fun_h) * A.coef * 2.0 * endd[i] * endd[j];
+                    if (pen_ed1 > 0) h += fabs(pen_fun_h) * A.coef * 2.0 * endd[R1 + i] * endd[R1 + j];
+                    if (i == j) h += A.stab;
+                    Lm[i * ld + j] += h;
+                }
+                F = F + fabs(F) * A.coef * (p0 * p0 + p1 * p1);                                 // distribution.py:355-357
+                F = F + 0.5 * A.stab * red[11];                                                 // distribution.py:358-359
+                __syncthreads();
+            }
         }
         // L D L^T in place, ONE workgroup barrier per column: step k only reads column k (never scales it), so the
         // trailing update A_ij -= A_ik A_jk / d_k needs no second barrier; afterwards Lm[i][k] = L_ik d_k (i > k) and
@@ -553,6 +647,8 @@ __global__ __launch_bounds__(COOP_THREADS) void k_me_coop(CoopArgs A) {
             continue;
         }
         spec = true;                                             // next round: partials at lam + pdir
+        alpha_try = 1.0;
+        ls_count = 0;
     }
     __syncthreads();
     if (b == 0) {
@@ -561,7 +657,14 @@ __global__ __launch_bounds__(COOP_THREADS) void k_me_coop(CoopArgs A) {
             for (int idx = tid; idx < R1 * R1; idx += COOP_THREADS) {
                 int i = idx / R1, j = idx % R1;
                 if (i > j) { const int t = i; i = j; j = t; }
-                A.H_out[idx] = A.tot[i * (2 * R1 - i + 1) / 2 + (j - i)];
+                double h = A.tot[i * (2 * R1 - i + 1) / 2 + (j - i)];
+                if (pen) {
+                    const int r = idx / R1, c = idx % R1;
+                    if (pen_ed0 > 0) h += fabs(pen_fun_h) * A.coef * 2.0 * endd[r] * endd[c];
+                    if (pen_ed1 > 0) h += fabs(pen_fun_h) * A.coef * 2.0 * endd[R1 + r] * endd[R1 + c];
+                    if (r == c) h += A.stab;
+                }
+                A.H_out[idx] = h;
             }
         if (tid == 0) {
             A.result[0] = (double)nit;
@@ -734,16 +837,15 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
     const int n_dblocks = (Q + 255) / 256;
     DevPool pool;
     // cooperative solver geometry: QS quadrature points per workgroup, NB workgroups
-    const bool use_pen_opts = (opts->penalty_coef != 0.0) || (opts->stab_penalty != 0.0);
     int QS = R1 <= 64 ? 32 : 16;
     while ((Q + QS - 1) / QS > COOP_MAX_BLOCKS) QS += 8;
     const int NB = (Q + QS - 1) / QS;
     const int R1p = R1 | 1;
     const size_t coop_E = (size_t)R1 * (R1 + 1) / 2 + R1 + 1;
     const size_t coop_alias = std::max((size_t)R1 * (R1 + 1), (size_t)QS * R1p);
-    const size_t coop_lds = sizeof(double) * ((size_t)QS * R1p + 6 * (size_t)R1 + 5 * (size_t)QS + 16 + 4 * COOP_MAX_BLOCKS + coop_alias);
+    const size_t coop_lds = sizeof(double) * ((size_t)QS * R1p + 9 * (size_t)R1 + 5 * (size_t)QS + 16 + 4 * COOP_MAX_BLOCKS + coop_alias);
     const bool stepwise_forced = getenv("MLMC_MAXENT_STEPWISE") != nullptr;             // validation aid (tests compare both paths)
-    const bool coop = !stepwise_forced && !use_pen_opts && n_prev == 0 && coop_lds <= 156 * 1024 && NB <= rt().n_cu;
+    const bool coop = !stepwise_forced && coop_lds <= 156 * 1024 && NB <= rt().n_cu;
     const size_t sizes[] = {(size_t)R1, (size_t)Q, (size_t)Q, (size_t)Q * R1, (size_t)Q, (size_t)R1, (size_t)R1, (size_t)R1, (size_t)R1,
                             (size_t)R1 * R1, (size_t)R1, (size_t)R1, 8, (size_t)n_dblocks, (size_t)2 * R1, (size_t)R1 + 1, 4, (size_t)4 * R1,
                             coop ? (size_t)NB * coop_E : 1, coop ? coop_E : 1, (size_t)2 * COOP_MAX_BLOCKS * 4, 16, 8,
@@ -818,6 +920,8 @@ int mlmc_maxent_solve(const mlmc_basis *b, const double *mu, const double *sigma
         ca.lam = d_lam.d(); ca.g_out = d_g.d(); ca.H_out = d_H.d(); ca.result = d_res.d();
         ca.part = d_part.d(); ca.tot = d_tot.d(); ca.part_ls = d_pls.d(); ca.bar = (unsigned *)d_bar.p;
         ca.Q = Q; ca.R1 = R1; ca.NB = NB; ca.QS = QS; ca.max_it = max_it; ca.tol = tol;
+        ca.end_diff = d_end.d(); ca.prev = d_prev.d(); ca.n_prev = n_prev; ca.use_pen = use_pen ? 1 : 0;
+        ca.stab = opts->stab_penalty; ca.coef = opts->penalty_coef;
         hipLaunchKernelGGL(k_me_coop, dim3(NB), dim3(COOP_THREADS), coop_lds, st, ca);
         MLMC_HIP_CHECK(hipGetLastError());
         // the final multipliers are written next to the result block: one copy brings everything back

@@ -1430,3 +1430,68 @@ def test_reference_style_moments_workflow(hip):
     assert np.allclose(np.mean(chunks_subsamples, axis=0), sample_vec, rtol=0.5)
     assert np.allclose(np.mean(chunks_means, axis=0), values_mean.mean, atol=1e-2)
     assert np.allclose(np.mean(chunks_vars, axis=0) / iters, values_mean.var, atol=1e-3)
+
+
+def test_penalised_solver_in_one_cooperative_launch(hip, monkeypatch):
+    """The penalised functional of tool/distribution.py (end-point decay, stabilisation toward the previous stage) inside the
+    cooperative Newton launch against the kernel-per-step loop (MLMC_MAXENT_STEPWISE=1): single stages with an ACTIVE decay
+    penalty and a stabilisation term, and the whole staged solve -- same success, multipliers, gradient, Hessian."""
+    import time
+    from mlmc_amd import Legendre
+    from mlmc_amd.tool import distribution as dd
+    from mlmc_amd.tool.simple_distribution import _solve_on_device
+    g6 = np.load(os.path.join(GOLDEN, "G6_maxent.npz"))
+
+    def both(fun):
+        out = []
+        for mode in ("coop", "step"):
+            if mode == "step":
+                monkeypatch.setenv("MLMC_MAXENT_STEPWISE", "1")
+            try:
+                t0 = time.perf_counter()
+                out.append((fun(), time.perf_counter() - t0))
+            finally:
+                monkeypatch.delenv("MLMC_MAXENT_STEPWISE", raising=False)
+        return out
+
+    # single stages: moments of a density that does NOT decay at the right end (the penalty is active), previous multipliers
+    dom = (0.0, 2.0)
+    for R, n_prev, stab in ((7, 0, 0.0), (11, 7, 0.05), (25, 21, 0.01), (70, 61, 0.02)):
+        fn = Legendre(R, dom)
+        x = np.linspace(dom[0], dom[1], 20001)
+        w = np.gradient(x)
+        pdf = np.exp(1.2 * x - 0.2 * x * x)
+        pdf /= np.sum(pdf * w)
+        mom = (fn.eval_all(x) * (pdf * w)[:, None]).sum(axis=0)
+        err = np.full(R, 1e-2)
+        err[0] = 1e-2 / 8
+        lam0 = np.zeros(R)
+        lam0[0] = -np.log(1.0 / (dom[1] - dom[0])) * err[0]
+        prev = 0.3 * np.cos(np.arange(n_prev)) * err[:n_prev] if n_prev else None
+
+        def stage():
+            return _solve_on_device(fn, mom, err, dom, lam0.copy(), tol=1e-7, max_it=200, n_intervals=64, gauss_degree=21,
+                                    stab_penalty=stab, penalty_coef=10, decay=(True, True), prev=prev)
+        ((l1, g1, h1, i1), t1), ((l2, g2, h2, i2), t2) = both(stage)
+        tag = (R, n_prev, stab)
+        # (a step is accepted when it lowers the gradient norm: near a tie the last bits decide, the two iterations may then
+        # take different step lengths for a while -- both must end at the same root)
+        assert i1.success == i2.success == 1 and abs(i1.nit - i2.nit) <= (1 if R < 50 else 4), (tag, i1.nit, i2.nit)
+        assert i1.grad_norm < 1e-7 and np.linalg.norm(g1) < 1e-7, (tag, i1.grad_norm)
+        scale = max(1.0, np.max(np.abs(l2)))
+        assert np.max(np.abs(l1 - l2)) < 1e-6 * scale, (tag, np.max(np.abs(l1 - l2)))
+        assert np.allclose(h1, h2, rtol=1e-6, atol=1e-9 * np.max(np.abs(h2))), tag
+        assert abs(i1.fun - i2.fun) <= 1e-9 * max(1.0, abs(i2.fun)) and abs(i1.moment0 - i2.moment0) < 1e-9, tag
+    # the staged solve of the reference interface, both ways
+    for name, R in (("norm12", 11), ("lognorm", 11)):
+        key = f"{name}_old_R{R}"
+        dom = tuple(g6[key + "_domain"])
+
+        def staged():
+            d = dd.Distribution(Legendre(R, dom), g6[key + "_moment_data"].copy(), domain=dom, force_decay=(True, True))
+            res = d.estimate_density_minimize(tol=1e-6, reg_param=0.01)
+            return d.multipliers.copy(), res
+        ((m1, r1), t1), ((m2, r2), t2) = both(staged)
+        assert r1.success and r2.success and abs(r1.nit - r2.nit) <= 2, (key, r1.nit, r2.nit)
+        assert np.max(np.abs(m1 - m2)) <= 1e-6 * np.max(np.abs(m2)), key
+        print("staged Distribution solve %s: cooperative %.2f ms, step by step %.2f ms (%d Newton steps)" % (key, 1e3 * t1, 1e3 * t2, r1.nit))
