@@ -162,6 +162,11 @@ static bool linearize_enabled() {
     return !(e && e[0] == '0');
 }
 
+static int lin_min_size() {      // covariances of more moments than this take the linearised mean (tuning aid)
+    const char *e = std::getenv("MLMC_HIP_LINEARIZE_MIN");
+    return e ? std::atoi(e) : 16;
+}
+
 static int need_runtime() {
     if (!rt().ready) return fail("mlmc_init has not been called (no HIP device bound)");
     return 0;
@@ -416,7 +421,7 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->d_out_s = a->d_out_nd + 2 * (size_t)n_levels;
     a->d_out_sp = a->d_out_s + (size_t)n_levels * a->K;
     // covariance WITH variances of 33..64 plain polynomial moments: mean through the product linearisation (mlmc_hip.h)
-    if (mode == MLMC_MODE_COV && !mean_only && !a->cov_from_values && b->out_size == 0 && b->p.size > 32 && b->p.size <= 64 &&
+    if (mode == MLMC_MODE_COV && !mean_only && !a->cov_from_values && b->out_size == 0 && b->p.size > lin_min_size() && b->p.size <= 64 &&
         (b->p.kind == MLMC_LEGENDRE || b->p.kind == MLMC_MONOMIAL) && linearize_enabled()) {
         std::vector<double> table;
         product_table(b->p.kind, a->R, table);
@@ -434,6 +439,10 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
             a->lin_basis->p.x_hi = b->p.x_hi;
             a->lin->host_outputs = false;                    // its totals are read on the device (launch_cov_finalize)
             a->lin_K = d.size;
+            // break-even of the auxiliary pass (three more launches per estimate, ~30 us) against the matrix time it saves
+            // (~80 ps per sample at 33..64 moments, ~9 ps at 17..32): measured with tools/kbench.py --n
+            const char *min_n = std::getenv("MLMC_HIP_LINEARIZE_MIN_N");
+            a->lin_min_n = min_n ? std::atoll(min_n) : (a->R > 32 ? 100000 : 1500000);
             hipError_t e = hipMalloc(&a->d_lin_prod, sizeof(double) * table.size());
             if (e == hipSuccess) e = hipMemcpy(a->d_lin_prod, table.data(), sizeof(double) * table.size(), hipMemcpyHostToDevice);
             if (e != hipSuccess) rc = fail(std::string("mlmc_accum_create: ") + hipGetErrorString(e));
@@ -455,6 +464,7 @@ int mlmc_accum_reset(mlmc_accum *a) {
     a->pending.clear();
     std::fill(a->level_flushed.begin(), a->level_flushed.end(), 0);
     MLMC_HIP_CHECK(hipMemsetAsync(a->d_state, 0, a->state_bytes, st));
+    a->lin_used = false;
     if (a->lin) return mlmc_accum_reset(a->lin);
     return 0;
 }
@@ -585,11 +595,13 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             }
         } else {
             // all components of a vector quantity in one launch (grid.y = component; they share the mask)
-            rc = m == 0 ? launch_cov_accum(a, level, 0, d_f, d_c, d_mask, n, count_in_kernel, a->mean_only ? 2 : (a->lin ? 3 : 0), a->n_comp) : 0;
+            const bool use_lin = a->lin && n >= a->lin_min_n;
+            rc = m == 0 ? launch_cov_accum(a, level, 0, d_f, d_c, d_mask, n, count_in_kernel, a->mean_only ? 2 : (use_lin ? 3 : 0), a->n_comp) : 0;
             // the extended moments of the linearised mean over the same chunk (same mask; the covariance kernel counts);
             // device chunks wait for finalize and go out as ONE launch over all levels; staged host chunks and the components of a
             // vector quantity (shared mask scratch) are launched when the push ends
-            if (!rc && a->lin)
+            if (!rc && use_lin) a->lin_used = true;
+            if (!rc && use_lin)
                 rc = launch_moments_accum(a->lin, level, m, f_m, c_m, d_mask, n, false, mem_kind == MLMC_DEVICE || a->n_comp > 1);
         }
         if (rc) return rc;

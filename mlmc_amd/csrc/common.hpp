@@ -132,6 +132,9 @@ struct mlmc_accum {
     mlmc_basis *lin_basis = nullptr;      // the family's member of size lin_K = 2 R - 1
     double *d_lin_prod = nullptr;         // [lin_K][R * R]: c_ijk, k-major
     int lin_K = 0;
+    int64_t lin_min_n = 0;                // chunks with fewer samples keep all three Gram matrices on the matrix cores (the
+                                          // extra launches of the auxiliary pass cost more than they save); sums are additive
+    bool lin_used = false;                // a chunk of this estimate went the linearised way
     std::vector<PendingSeg> pending;   // MOMENTS: chunks gathered into one launch (flushed by finalize / conflicts)
 };
 

@@ -144,8 +144,8 @@ __device__ __forceinline__ void cov_spline_store(const TermGen<MLMC_SPLINE> &g, 
 
 // MODE 0: G0, G1, G2 (covariance mean + variance);  MODE 1: G = D^T D only (variance of transformed moments);
 // MODE 2: G0 = D^T S only (covariance mean without its variance, e.g. Estimate.construct_density)
-// MODE 3 (64-term kernel only): G1, G2 without G0 -- the variance of the covariance, its mean coming from the level sums of
-// the 2 R - 1 moments of the product linearisation (api.hip: lin accumulator)
+// MODE 3: G1, G2 without G0 -- the variance of the covariance, its mean coming from the level sums of the 2 R - 1 moments of
+// the product linearisation (api.hip: lin accumulator)
 // BI, BJ (T = 4 only): the 64 x 64 output block (rows = terms [64 BI, 64 BI + 64), columns = terms [64 BJ, ...)) of
 // a covariance with more than 64 moments; off-diagonal blocks keep two term windows in LDS (one workgroup per CU).
 // VALS: `fine` / `coarse` hold already evaluated moment values [n][R] (row-major, NaN rows = masked samples) instead
@@ -165,7 +165,11 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
     constexpr int BATCH = cov_batch(T, BI != BJ, VALS, PAIR);
     constexpr int STRIDE = BATCH + 2;          // doubles per term row: == 2 (mod 32) -> ds_read_b64 fragments hit 32 distinct bank pairs
     constexpr int NSL = 4 / T;                 // k-slices (waves sharing a row tile split the samples)
-    constexpr int NG = (MODE == 0) ? (PAIR ? 3 : 2) : 1;
+    // MODE 3 in THIS kernel: MODE 0 without the G0 instructions -- same accumulator sets and partial layout, the G0 slot stays
+    // zero (the 64-term kernel has its own two-matrix layout)
+    constexpr bool M0 = MODE == 0 || MODE == 3;
+    constexpr bool DO_G0 = MODE == 0;
+    constexpr int NG = M0 ? (PAIR ? 3 : 2) : 1;
     constexpr bool WIDE = BI != BJ;            // two different term windows
     constexpr int TA = 64 * BI, TB = 64 * BJ;  // first term of the row / column window
     constexpr int N_EVAL = (BI > BJ ? TA : TB) + NT;   // terms the recurrence has to run through
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
     // blockIdx.y = component of a vector quantity ([M][n] arrays, one mask for all): its own samples and partial rows
     fine += (int64_t)blockIdx.y * n;
     if (PAIR) coarse += (int64_t)blockIdx.y * n;
-    partials += (int64_t)blockIdx.y * gridDim.x * ((T <= 2 && BI == BJ) ? 4 : 4 / T) * (((MODE == 0) ? 3 : 1) * (16 * T) * (16 * T));
+    partials += (int64_t)blockIdx.y * gridDim.x * ((T <= 2 && BI == BJ) ? 4 : 4 / T) * ((M0 ? 3 : 1) * (16 * T) * (16 * T));
     if (blockIdx.y) pcounts = nullptr;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
                         d[i] = f - c;
                         sv[i] = f + c;
                     }
-                    if (MODE == 0) {
+                    if (M0) {
                         dd[i] = d[i] * d[i];
                         ss[i] = sv[i] * sv[i];
                         ds[i] = d[i] * sv[i];
@@ -304,8 +308,8 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
 #pragma unroll
                     for (int j = 0; j < T; ++j) {
                         const bool upper = j >= i;
-                        if (MODE == 0) {
-                            if (PAIR || upper) acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[i], sv[j], acc[0][i][j], 0, 0, 0);
+                        if (M0) {
+                            if (DO_G0 && (PAIR || upper)) acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[i], sv[j], acc[0][i][j], 0, 0, 0);
                             if (PAIR || upper) acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[i], ss[j], acc[1][i][j], 0, 0, 0);
                             if (PAIR && upper) acc[NG - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ds[i], ds[j], acc[NG - 1][i][j], 0, 0, 0);
                         } else if (MODE == 1 || !PAIR) {
@@ -345,8 +349,8 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
                     db = fb - cb;
                     sb = fb + cb;
                 }
-                if (MODE == 0) {
-                    acc[0][0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, sb, acc[0][0][J], 0, 0, 0);
+                if (M0) {
+                    if (DO_G0) acc[0][0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, sb, acc[0][0][J], 0, 0, 0);
                     if (PAIR) {
                         acc[1][0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sb * sb, acc[1][0][J], 0, 0, 0);
                         acc[2][0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, db * sb, acc[2][0][J], 0, 0, 0);
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
 #endif
     // ---------------- write the workgroup's partial tiles ----------------
     // partial row = (block, kslice); columns [g][row][col] with g in {G0, G1, G2} (MODE 0) or {G} (MODE 1)
-    constexpr int NGOUT = (MODE == 0) ? 3 : 1;
+    constexpr int NGOUT = M0 ? 3 : 1;
     // SLICED: one partial row per wave (its k-slice) holding all tiles; else one per (block, kslice), a wave writes row tile I
     double *__restrict__ prow = partials + (SLICED ? ((int64_t)blockIdx.x * 4 + wave) : ((int64_t)blockIdx.x * NSL + kslice)) * (NGOUT * NT * NT);
 #pragma unroll
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
                 const bool low = SLICED && J < It;
                 // acc of tile (J, It) holds element (16 J + lane / 16 + 4 r, 16 It + lane % 16): it is written transposed
                 const int mirror = (16 * It + (lane & 15)) * NT + (16 * J + (lane >> 4) + 4 * r);
-                if (MODE == 0) {
+                if (M0) {
                     if (PAIR) {
                         prow[0 * NT * NT + row * NT + col] = acc[0][Iw][J][r];
                         prow[1 * NT * NT + row * NT + col] = acc[1][Iw][J][r];
@@ -854,6 +858,7 @@ static int launch_cov_kind(const BasisParams &bp, int T, int bi, int bj, bool pa
     if (T == 1) return launch_cov_t<KIND, 1, MODE, 0, 0>(MLMC_COV_ARGS);
     if (T == 2) return launch_cov_t<KIND, 2, MODE, 0, 0>(MLMC_COV_ARGS);
     if (bi == 0 && bj == 0) return launch_cov_t<KIND, 4, MODE, 0, 0>(MLMC_COV_ARGS);
+    if constexpr (MODE == 3) return fail("covariance: the variance-only pass covers 64 moments");     // (no two-window code for it)
     if (bi == 0 && bj == 1) return launch_cov_t<KIND, 4, MODE, 0, 1>(MLMC_COV_ARGS);
     if (bi == 1 && bj == 0) return launch_cov_t<KIND, 4, MODE, 1, 0>(MLMC_COV_ARGS);
     if (bi == 1 && bj == 1) return launch_cov_t<KIND, 4, MODE, 1, 1>(MLMC_COV_ARGS);
@@ -1101,7 +1106,7 @@ static int launch_spline_band(mlmc_accum *a, int level, int comp, const double *
 // x 512 = executed matrix-core flops per sample (mlmc_accum_kernel_flops).
 static int cov_tiles_per_sample(int T, bool diagonal, bool pair, int gram_mode) {
     const int full = T * T, upper = T * (T + 1) / 2;
-    if (!diagonal) return (gram_mode == 0 ? (pair ? 3 : 2) : 1) * full;      // two term windows: no symmetry inside the block
+    if (!diagonal) return (gram_mode == 0 ? (pair ? 3 : 2) : (gram_mode == 3 ? (pair ? 2 : 1) : 1)) * full;      // two term windows: no symmetry inside the block
     if (gram_mode == 0) return pair ? 2 * full + upper : 2 * upper;
     if (gram_mode == 3) return pair ? full + upper : upper;
     if (gram_mode == 1 || !pair) return upper;
@@ -1120,19 +1125,21 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
     hipStream_t st = rt().stream;
     const int T = (R <= 16) ? 1 : (R <= 32 ? 2 : 4);
     const int NT = 16 * T, NSL = 4 / T;
-    const int NG = cov_ng(gram_mode);
     const int NB = (R + 63) / 64;          // 64 x 64 output blocks per dimension
-    if (gram_mode == 3 && !(T == 4 && NB == 1)) return fail("covariance: the variance-only pass exists for 33..64 moments");
     const bool pair = d_c != nullptr;
     const int64_t bsz = T == 4 ? (pair ? COV_T4_BATCH : 2 * COV_T4_BATCH) : cov_batch(T, false, false, pair);
     const int64_t n_batches = (n + bsz - 1) / bsz;
-    const size_t width = (size_t)NG * NT * NT;
     const BasisParams &bp = a->basis->p;
-    double *totals = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0) +
-                     (gram_mode == 3 ? (int64_t)a->RP * a->RP : 0);      // variance only: the partial rows hold [G1][G2]
+    double *totals0 = a->d_totals + ((int64_t)level * a->n_comp + comp) * a->int_width + (diff_gram_only ? 2 * (int64_t)R : 0);
     for (int bi = 0; bi < NB; ++bi)
         for (int bj = 0; bj < NB; ++bj) {
             if (!pair && bj < bi) continue;   // level 0: symmetric matrices, block (bj, bi) is mirrored by the reduction
+            // variance only (gram_mode 3): the 64-term kernel of the diagonal blocks leaves [G1][G2] in its partial rows, the
+            // generic kernel keeps the three-matrix layout with an empty G0
+            const bool two_slots = gram_mode == 3 && T == 4 && bi == bj;
+            const int NG = gram_mode == 3 ? (two_slots ? 2 : 3) : cov_ng(gram_mode);
+            const size_t width = (size_t)NG * NT * NT;
+            double *totals = totals0 + (two_slots ? (int64_t)a->RP * a->RP : 0);
             // workgroups per CU: one for the two-window blocks (135 KB of LDS), four for a single 16-term tile (33 KB each:
             // -11..15 % time against two), two otherwise
             int blocks = rt().n_cu * ((bi != bj) ? ((pair && MLMC_COV_WIDE_BATCH < 64) ? 2 : 1) : (T == 1 ? 4 : (T == 4 ? COV_T4_WGS : 2)));
@@ -1148,18 +1155,25 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
             if (timed) if (int rc = timing_begin(a)) return rc;
             int rc;
 #define MLMC_COV_DISPATCH(KIND)                                                                                               \
-    rc = gram_mode == 3 ? launch_cov_t<KIND, 4, 3, 0, 0>(bp, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc)      \
+    rc = gram_mode == 3 ? launch_cov_kind<KIND, 3>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
        : gram_mode == 2 ? launch_cov_kind<KIND, 2>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
        : diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
                         : launch_cov_kind<KIND, 0>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc)
+#define MLMC_COV_DISPATCH012(KIND)                                                                                            \
+    rc = gram_mode == 2 ? launch_cov_kind<KIND, 2>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
+       : diff_gram_only ? launch_cov_kind<KIND, 1>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc) \
+                        : launch_cov_kind<KIND, 0>(bp, T, bi, bj, pair, blocks, ncomp, d_f, d_c, d_mask, n, R, a->d_partials, pc)
+            if (gram_mode == 3 && bp.kind != MLMC_LEGENDRE && bp.kind != MLMC_MONOMIAL)
+                return fail("covariance: the variance-only pass exists for the polynomial families");
             switch (bp.kind) {
                 case MLMC_LEGENDRE: MLMC_COV_DISPATCH(MLMC_LEGENDRE); break;
                 case MLMC_MONOMIAL: MLMC_COV_DISPATCH(MLMC_MONOMIAL); break;
-                case MLMC_FOURIER: MLMC_COV_DISPATCH(MLMC_FOURIER); break;
-                case MLMC_SPLINE: MLMC_COV_DISPATCH(MLMC_SPLINE); break;
+                case MLMC_FOURIER: MLMC_COV_DISPATCH012(MLMC_FOURIER); break;      // (no product linearisation here: no MODE 3 code)
+                case MLMC_SPLINE: MLMC_COV_DISPATCH012(MLMC_SPLINE); break;
                 default: return fail("covariance: unsupported basis kind");
             }
 #undef MLMC_COV_DISPATCH
+#undef MLMC_COV_DISPATCH012
             if (rc) return rc;
             if (timed) {
                 if (int rc2 = timing_end(a)) return rc2;
@@ -1217,11 +1231,11 @@ __global__ void k_cov_lin_mean(const double *__restrict__ prod, const double *__
     if (idx >= RR) return;
     double acc = 0.0;
     for (int k = 0; k < K; ++k) acc = __builtin_fma(prod[(int64_t)k * RR + idx], m_s[k], acc);
-    out_s[(int64_t)lc * RR + idx] = acc;
+    out_s[(int64_t)lc * RR + idx] += acc;         // (+ the G0 sums of the chunks that kept all three Gram matrices)
 }
 
 int launch_cov_finalize(mlmc_accum *a) {
-    if (a->lin) {
+    if (a->lin && a->lin_used) {
         if (int rc = flush_moments(a->lin)) return rc;
     }
     const int n_lc = a->n_levels * a->n_comp;
@@ -1232,7 +1246,7 @@ int launch_cov_finalize(mlmc_accum *a) {
                        a->RP, a->int_width, a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n, a->d_out_nd,
                        a->mean_only ? 1 : 0);
     MLMC_HIP_CHECK(hipGetLastError());
-    if (a->lin) {       // G0 was not accumulated (gram_mode 3): the means come from the extended moments
+    if (a->lin && a->lin_used) {       // chunks without G0 (gram_mode 3): their share of the means comes from the extended moments
         hipLaunchKernelGGL(k_cov_lin_mean, dim3((R * R + 255) / 256, n_lc), dim3(256), sizeof(double) * a->lin_K, rt().stream,
                            a->d_lin_prod, a->lin->d_totals, a->lin_basis->d_scale, R, a->lin_K, a->lin->int_width, a->d_out_s);
         MLMC_HIP_CHECK(hipGetLastError());

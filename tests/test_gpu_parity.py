@@ -1138,21 +1138,24 @@ def test_adaptive_sampling_loop_matches_reference_trajectory(hip):
         assert np.allclose(means, case["means"], rtol=0, atol=1e-10) and np.allclose(vars_, case["vars"], rtol=1e-9, atol=1e-16)
 
 
-@pytest.mark.parametrize("R", [33, 40, 64])
+@pytest.mark.parametrize("R", [17, 32, 33, 40, 64])
 def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
-    """Covariance WITH variances of 33..64 plain polynomial moments: the matrix cores accumulate the variance Grams only, the
+    """Covariance WITH variances of 17..64 plain polynomial moments: the matrix cores accumulate the variance Grams only, the
     means come from the level sums of the 2 R - 1 moments of the family (mlmc_hip.h, mlmc_accum_aux_kernel_time).  Against the
     oracle, and against the same library with all three Gram matrices on the matrix cores (MLMC_HIP_LINEARIZE=0): identical
     counts, bit-identical second-moment sums, means equal to rounding; host chunks, several chunks per level, a two-component
-    quantity with its shared mask, and log=True moments."""
+    quantity with its shared mask, and log=True moments.  The choice is made per chunk (small chunks keep all three Gram
+    matrices: the sums are additive), MLMC_HIP_LINEARIZE_MIN_N sets the chunk size from which the linearised way is taken:
+    0 here, and 1500 for a mix of both kinds of chunk in one estimate."""
     import torch
     from mlmc_amd import Legendre, Monomial
     from mlmc_amd.engine import LevelAccumulator
     dom = (-3.7190164854556804, 3.7190164854556804)
     levels = level_arrays([5301, 2500, 1777], [0.5, 0.07, 0.01], 1, 19)
 
-    def both(fn, lv, n_comp=1, device=False, split=False):
+    def both(fn, lv, n_comp=1, device=False, split=False, min_n="0"):
         out = []
+        monkeypatch.setenv("MLMC_HIP_LINEARIZE_MIN_N", min_n)
         for lin in ("1", "0"):
             monkeypatch.setenv("MLMC_HIP_LINEARIZE", lin)
             acc = LevelAccumulator(fn, len(lv), LevelAccumulator.COV, n_comp=n_comp)
@@ -1168,9 +1171,9 @@ def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
                         keep.append((fa, ca))
                     acc.push(l, fa, ca)
             out.append(acc.finalize())
-            aux = acc.aux_kernel_time()
             acc.close()
         monkeypatch.delenv("MLMC_HIP_LINEARIZE")
+        monkeypatch.delenv("MLMC_HIP_LINEARIZE_MIN_N")
         (n, n_rm, s, sp), (n0, n_rm0, s0, sp0) = out
         assert np.array_equal(n, n0) and np.array_equal(n_rm, n_rm0)
         assert np.array_equal(sp, sp0)                                    # the same instructions in the same order
@@ -1188,6 +1191,9 @@ def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
             assert np.array_equal(cov, cov.T)
             S = s.reshape(len(levels), R, R)
             assert S[0, 0, 0] == float(n[0]) and not S[1:, 0, 0].any()
+        # chunks of 1767 | 3534, 833 | 1667, 592 | 1185 samples: direct and linearised contributions in one level
+        n, n_rm, s, sp = both(cls(R, dom), levels, device=True, split=True, min_n="1500")
+        _check_against(n, n_rm, s, sp, ref)
     # two components: a sample is dropped when any component is masked
     lv2 = level_arrays([2800, 1100], [0.3, 0.02], 2, 6)
     b = onp.Basis(onp.LEGENDRE, R, dom)
