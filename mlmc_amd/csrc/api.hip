@@ -420,7 +420,7 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->d_out_nd = (double *)(a->d_out_n + 2 * (size_t)n_levels);
     a->d_out_s = a->d_out_nd + 2 * (size_t)n_levels;
     a->d_out_sp = a->d_out_s + (size_t)n_levels * a->K;
-    // covariance WITH variances of 33..64 plain polynomial moments: mean through the product linearisation (mlmc_hip.h)
+    // covariance WITH variances of 17..64 plain polynomial moments: mean through the product linearisation (mlmc_hip.h)
     if (mode == MLMC_MODE_COV && !mean_only && !a->cov_from_values && b->out_size == 0 && b->p.size > lin_min_size() && b->p.size <= 64 &&
         (b->p.kind == MLMC_LEGENDRE || b->p.kind == MLMC_MONOMIAL) && linearize_enabled()) {
         std::vector<double> table;

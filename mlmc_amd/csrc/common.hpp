@@ -125,7 +125,7 @@ struct mlmc_accum {
     int64_t launches = 0, alg_bytes = 0;
     int64_t mfma_flops = 0;   // executed matrix-core flops of the timed covariance launches (mlmc_accum_kernel_flops)
     int RP = 0;  // COV: R padded to 16
-    // COV with variances of 33..64 plain Legendre / monomial moments: the MEAN of the covariance comes from the level sums of
+    // COV with variances of 17..64 plain Legendre / monomial moments: the MEAN of the covariance comes from the level sums of
     // the 2 R - 1 moments of the product linearisation (phi_i phi_j = sum_k c_ijk phi_k) -- an inner mean-only MOMENTS
     // accumulator over the same chunks -- and the matrix cores compute G1, G2 only (26 instead of 42 tiles per pair)
     mlmc_accum *lin = nullptr;
