@@ -152,8 +152,8 @@ int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t
  * form count 6 R^2 per pair (quantity_estimate.py:131-147); it is the numerator of a physical matrix-pipe fraction.
  * Returns the total and clears it. */
 int mlmc_accum_kernel_flops(mlmc_accum *a, int64_t *mfma_flops);
-/* A MLMC_MODE_COV accumulator WITH variances of 17..64 plain Legendre or monomial moments splits the work of its large chunks
- * (>= 10^5 samples at 33..64 moments, >= 1.5 x 10^6 at 17..32; MLMC_HIP_LINEARIZE_MIN_N overrides; smaller chunks keep all
+/* A MLMC_MODE_COV accumulator WITH variances of 17..128 plain Legendre or monomial moments splits the work of its large chunks
+ * (>= 10^5 samples at 33..128 moments, >= 1.5 x 10^6 at 17..32; MLMC_HIP_LINEARIZE_MIN_N overrides; smaller chunks keep all
  * three Gram matrices, the level sums are additive): the matrix cores
  * accumulate only the two Gram matrices of the VARIANCE (G1, G2: 26 instead of 42 tiles per pair at R = 64), and the MEAN
  * (quantity_estimate.py:131-147 + :59-65: level sums of f_i f_j - c_i c_j) comes from the level sums of the 2 R - 1 moments

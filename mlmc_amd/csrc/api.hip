@@ -384,7 +384,7 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     // plain polynomial moments with 64 < R <= 128: the mean-only form of the term-split kernel covers them in ONE pass
     // (moments.hip, k_moments_accum_split<..., SQ = false>); every other plain size keeps its free sums of squares
     a->mean_only_plain = mean_only && mode == MLMC_MODE_MOMENTS && b->out_size == 0 &&
-                         (b->p.kind == MLMC_LEGENDRE || b->p.kind == MLMC_MONOMIAL) && b->p.size > 64 && b->p.size <= 128;
+                         (b->p.kind == MLMC_LEGENDRE || b->p.kind == MLMC_MONOMIAL) && b->p.size > 64 && b->p.size <= 256;
     a->n_comp = n_comp;
     a->R = b->p.size;
     a->Rout = b->out_size > 0 ? b->out_size : b->p.size;
@@ -420,8 +420,8 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->d_out_nd = (double *)(a->d_out_n + 2 * (size_t)n_levels);
     a->d_out_s = a->d_out_nd + 2 * (size_t)n_levels;
     a->d_out_sp = a->d_out_s + (size_t)n_levels * a->K;
-    // covariance WITH variances of 17..64 plain polynomial moments: mean through the product linearisation (mlmc_hip.h)
-    if (mode == MLMC_MODE_COV && !mean_only && !a->cov_from_values && b->out_size == 0 && b->p.size > lin_min_size() && b->p.size <= 64 &&
+    // covariance WITH variances of 17..128 plain polynomial moments: mean through the product linearisation (mlmc_hip.h)
+    if (mode == MLMC_MODE_COV && !mean_only && !a->cov_from_values && b->out_size == 0 && b->p.size > lin_min_size() && b->p.size <= 128 &&
         (b->p.kind == MLMC_LEGENDRE || b->p.kind == MLMC_MONOMIAL) && linearize_enabled()) {
         std::vector<double> table;
         product_table(b->p.kind, a->R, table);

@@ -92,7 +92,7 @@ struct mlmc_accum {
     int n_levels = 0, mode = 0, n_comp = 1;
     bool mean_only = false;       // MLMC_MODE_MEAN_ONLY: the second moments (sp) are not accumulated
     bool cov_from_values = false; // COV: accumulated from materialised moment values (TransformedMoments; plain bases with R > 128)
-    bool mean_only_plain = false; // ... requested for MOMENTS of a plain basis: honoured by the 65..128-term split kernel (sp = NaN)
+    bool mean_only_plain = false; // ... requested for MOMENTS of a plain basis: honoured by the 65..256-term split kernel (sp = NaN)
     int R = 0;            // underlying family size
     int Rout = 0;         // rows per component seen by the caller (transform applied)
     int64_t K = 0;        // caller rows per level = n_comp * Rout (* Rout)
@@ -125,7 +125,7 @@ struct mlmc_accum {
     int64_t launches = 0, alg_bytes = 0;
     int64_t mfma_flops = 0;   // executed matrix-core flops of the timed covariance launches (mlmc_accum_kernel_flops)
     int RP = 0;  // COV: R padded to 16
-    // COV with variances of 17..64 plain Legendre / monomial moments: the MEAN of the covariance comes from the level sums of
+    // COV with variances of 17..128 plain Legendre / monomial moments: the MEAN of the covariance comes from the level sums of
     // the 2 R - 1 moments of the product linearisation (phi_i phi_j = sum_k c_ijk phi_k) -- an inner mean-only MOMENTS
     // accumulator over the same chunks -- and the matrix cores compute G1, G2 only (26 instead of 42 tiles per pair)
     mlmc_accum *lin = nullptr;

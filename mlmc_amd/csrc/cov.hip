@@ -858,7 +858,6 @@ static int launch_cov_kind(const BasisParams &bp, int T, int bi, int bj, bool pa
     if (T == 1) return launch_cov_t<KIND, 1, MODE, 0, 0>(MLMC_COV_ARGS);
     if (T == 2) return launch_cov_t<KIND, 2, MODE, 0, 0>(MLMC_COV_ARGS);
     if (bi == 0 && bj == 0) return launch_cov_t<KIND, 4, MODE, 0, 0>(MLMC_COV_ARGS);
-    if constexpr (MODE == 3) return fail("covariance: the variance-only pass covers 64 moments");     // (no two-window code for it)
     if (bi == 0 && bj == 1) return launch_cov_t<KIND, 4, MODE, 0, 1>(MLMC_COV_ARGS);
     if (bi == 1 && bj == 0) return launch_cov_t<KIND, 4, MODE, 1, 0>(MLMC_COV_ARGS);
     if (bi == 1 && bj == 1) return launch_cov_t<KIND, 4, MODE, 1, 1>(MLMC_COV_ARGS);

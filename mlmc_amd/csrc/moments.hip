@@ -468,7 +468,7 @@ __device__ __forceinline__ void split_import(TermGen<KIND> &g, const double *__r
 #ifndef MLMC_SPLIT_NS
 #define MLMC_SPLIT_NS 2
 #endif
-template <int KIND, bool PAIR, bool PLAIN, int HT, int TT, bool SQ, int NS>
+template <int KIND, bool PAIR, bool PLAIN, int HT, int TT, bool SQ, int NS, int T0 = 0>
 __device__ __forceinline__ void split_head(const BasisParams &bp, const double *__restrict__ fine, const double *__restrict__ coarse,
                                            const uint8_t *__restrict__ mask, int64_t n, int bid, int nb, int n_trips,
                                            double *__restrict__ hand, double (&s)[split_max(HT, TT)], double (&sp)[split_max(HT, TT)],
@@ -518,12 +518,22 @@ __device__ __forceinline__ void split_head(const BasisParams &bp, const double *
             gf[q].init(keep ? tf : 0.0, w, bp);
             if (PAIR) gc[q].init(keep ? tc : 0.0, w, bp);
         }
+        if (T0 > 0) {      // second term window (terms [T0, T0 + HT + TT)): advance the recurrences without accumulating
+#pragma unroll
+            for (int i = 0; i < T0; ++i) {
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    gf[q].next(i);
+                    if (PAIR) gc[q].next(i);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < HT; ++i) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                double d = gf[q].next(i);
-                if (PAIR) d -= gc[q].next(i);
+                double d = gf[q].next(T0 + i);
+                if (PAIR) d -= gc[q].next(T0 + i);
                 s[i] += d;
                 if (SQ) sp[i] = __builtin_fma(d, d, sp[i]);
             }
@@ -539,7 +549,7 @@ __device__ __forceinline__ void split_head(const BasisParams &bp, const double *
     __syncthreads();      // the tail's last trip
 }
 
-template <int KIND, bool PAIR, int HT, int TT, bool SQ, int NS>
+template <int KIND, bool PAIR, int HT, int TT, bool SQ, int NS, int T0 = 0>
 __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, const double *__restrict__ hand,
                                            double (&s)[split_max(HT, TT)], double (&sp)[split_max(HT, TT)]) {
     const int l128 = threadIdx.x & (SPLIT_LANES - 1);
@@ -558,8 +568,8 @@ __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, c
         for (int i = 0; i < TT; ++i) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                double d = gf[q].next(HT + i);
-                if (PAIR) d -= gc[q].next(HT + i);
+                double d = gf[q].next(T0 + HT + i);
+                if (PAIR) d -= gc[q].next(T0 + HT + i);
                 s[i] += d;
                 if (SQ) sp[i] = __builtin_fma(d, d, sp[i]);
             }
@@ -574,7 +584,9 @@ __device__ __forceinline__ void split_tail(const BasisParams &bp, int n_trips, c
 // registers, so ONE pass covers up to 128 terms (62 + 66) at 6 instead of 7 instructions per term and pair: the pass behind
 // `estimate_mean(covariance(q, fn), variance=False)` for Legendre / monomial moments, whose R x R level means follow
 // from the level sums of 2 R - 1 moments (mlmc_amd/linearize.py; Estimate.construct_density, estimator.py:304-331).
-template <int KIND, bool PLAIN, int HT, int TT, int WPS, bool SQ = true, int NS = MLMC_SPLIT_NS>
+// T0 > 0: the window of terms [T0, T0 + HT + TT) -- the second pass of a mean-only estimate of 129..256 moments (the head
+// first walks T0 recurrence steps without accumulating, so it gets the smaller share of the accumulating terms).
+template <int KIND, bool PLAIN, int HT, int TT, int WPS, bool SQ = true, int NS = MLMC_SPLIT_NS, int T0 = 0>
 __global__ __launch_bounds__(ACC_THREADS, WPS) void k_moments_accum_split(BasisParams bp, SegTable tab,
                                                                         double *__restrict__ partials,
                                                                         int64_t *__restrict__ pcounts) {
@@ -599,11 +611,11 @@ __global__ __launch_bounds__(ACC_THREADS, WPS) void k_moments_accum_split(BasisP
     for (int i = 0; i < MAXT; ++i) { s[i] = 0.0; sp[i] = 0.0; }
     int n_keep = 0, n_rm = 0;
     if (wave < 2) {
-        if (sg.coarse) split_head<KIND, true, PLAIN, HT, TT, SQ, NS>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
-        else split_head<KIND, false, PLAIN, HT, TT, SQ, NS>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
+        if (sg.coarse) split_head<KIND, true, PLAIN, HT, TT, SQ, NS, T0>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
+        else split_head<KIND, false, PLAIN, HT, TT, SQ, NS, T0>(bp, sg.fine, sg.coarse, sg.mask, sg.n, bid, sg.nblocks, n_trips, hand, s, sp, n_keep, n_rm);
     } else {
-        if (sg.coarse) split_tail<KIND, true, HT, TT, SQ, NS>(bp, n_trips, hand, s, sp);
-        else split_tail<KIND, false, HT, TT, SQ, NS>(bp, n_trips, hand, s, sp);
+        if (sg.coarse) split_tail<KIND, true, HT, TT, SQ, NS, T0>(bp, n_trips, hand, s, sp);
+        else split_tail<KIND, false, HT, TT, SQ, NS, T0>(bp, n_trips, hand, s, sp);
     }
     // ---- block partial: butterfly sums inside every wave (fixed order), then head pair / tail pair added in fixed order ----
 #pragma unroll
@@ -871,23 +883,26 @@ static int accum_dispatch(int op, bool plain, const BasisParams &bp, int rt_sel,
 }
 
 // term-split kernel (48 < R <= 64; mean-only: 64 < R <= 128): op 0: *out = resident blocks per CU; op 1: launch
-template <int KIND, bool PLAIN, int HT, int TT, int WPS, bool SQ>
+template <int KIND, bool PLAIN, int HT, int TT, int WPS, bool SQ, int T0 = 0>
 static int split_go(int op, const BasisParams &bp, const SegTable *tab, int total_blocks, double *partials, int64_t *pcounts, int *out) {
     if (op == 0) {
-        MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(out, (const void *)k_moments_accum_split<KIND, PLAIN, HT, TT, WPS, SQ>, ACC_THREADS, 0));
+        MLMC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(out, (const void *)k_moments_accum_split<KIND, PLAIN, HT, TT, WPS, SQ, MLMC_SPLIT_NS, T0>, ACC_THREADS, 0));
         return 0;
     }
-    hipLaunchKernelGGL((k_moments_accum_split<KIND, PLAIN, HT, TT, WPS, SQ>), dim3(total_blocks), dim3(ACC_THREADS), 0, rt().stream, bp, *tab, partials, pcounts);
+    hipLaunchKernelGGL((k_moments_accum_split<KIND, PLAIN, HT, TT, WPS, SQ, MLMC_SPLIT_NS, T0>), dim3(total_blocks), dim3(ACC_THREADS), 0, rt().stream, bp, *tab, partials, pcounts);
     MLMC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 // terms of the head of the mean-only variants: the head also loads, transforms and counts (~50 instructions per trip)
 constexpr int SPLIT_MEAN_HEAD_96 = 46, SPLIT_MEAN_HEAD_128 = 62;
-// n_split: terms of the instantiation -- 64 (mean + variance), 96 or 128 (mean only)
-static int split_dispatch(int op, bool plain, const BasisParams &bp, int n_split, const SegTable *tab, int total_blocks, double *partials,
+// second window (terms 128..255): the head walks 128 steps (4 instructions per pair and step) before its accumulating terms
+constexpr int SPLIT_MEAN_HEAD_W2 = 40;
+// n_split: terms of the instantiation -- 64 (mean + variance), 96 or 128 (mean only); t0 = 128: the second window (mean only)
+static int split_dispatch(int op, bool plain, const BasisParams &bp, int n_split, int t0, const SegTable *tab, int total_blocks, double *partials,
                           int64_t *pcounts, int *out) {
 #define MLMC_SPLIT_GO(KIND, P)                                                                                                          \
-    (n_split == 64 ? split_go<KIND, P, SPLIT_HEAD, 64 - SPLIT_HEAD, MLMC_SPLIT_WPS, true>(op, bp, tab, total_blocks, partials, pcounts, out)   \
+    (t0 == 128 ? split_go<KIND, P, SPLIT_MEAN_HEAD_W2, 128 - SPLIT_MEAN_HEAD_W2, 2, false, 128>(op, bp, tab, total_blocks, partials, pcounts, out) \
+     : n_split == 64 ? split_go<KIND, P, SPLIT_HEAD, 64 - SPLIT_HEAD, MLMC_SPLIT_WPS, true>(op, bp, tab, total_blocks, partials, pcounts, out)   \
      : n_split == 96 ? split_go<KIND, P, SPLIT_MEAN_HEAD_96, 96 - SPLIT_MEAN_HEAD_96, 2, false>(op, bp, tab, total_blocks, partials, pcounts, out) \
                      : split_go<KIND, P, SPLIT_MEAN_HEAD_128, 128 - SPLIT_MEAN_HEAD_128, 2, false>(op, bp, tab, total_blocks, partials, pcounts, out))
     if (bp.kind == MLMC_LEGENDRE) return plain ? MLMC_SPLIT_GO(MLMC_LEGENDRE, true) : MLMC_SPLIT_GO(MLMC_LEGENDRE, false);
@@ -915,22 +930,22 @@ int flush_moments(mlmc_accum *a) {
     const bool poly64 = poly && R > 48 && R <= 64;
     // mean-only estimate of plain polynomial moments with 64 < R <= 128: ONE pass of the term-split kernel without the sums
     // of squares (k_moments_accum_split<..., SQ = false>)
-    const bool split_mean = poly && a->mean_only_plain && R > 64 && R <= 128 && !no_split;
-    const int n_split = split_mean ? (R <= 96 ? 96 : 128) : 64;
+    const bool split_mean = poly && a->mean_only_plain && R > 64 && R <= 256 && !no_split;
     const bool split = (poly64 && !no_split) || split_mean;
     const int pass_terms = split_mean ? 128 : ((poly64 && !split) ? 32 : MAX_TERMS_PER_PASS);
     for (int t0 = 0; t0 < (sparse_spline ? 1 : R); t0 += pass_terms) {
         const int n_terms = (R - t0 < pass_terms) ? R - t0 : pass_terms;
+        const int n_split = split_mean ? ((t0 == 0 && R <= 96) ? 96 : 128) : 64;
         const int rt_sel = sparse_spline ? R : (split ? n_split : pick_rt(bp.kind, n_terms, t0));
         const int width = 2 * rt_sel;
         int per_cu = 4;
         bool plain = bp.kind != MLMC_IDENTITY && !bp.is_log && bp.is_clip;
         for (const PendingSeg &p : a->pending) plain = plain && p.mask == nullptr;
         if (split) {
-            static int occ_split[2][2][3];   // [Legendre | monomial][plain][64 | 96 | 128 terms]; 0 = not asked yet
-            int &cached = occ_split[bp.kind == MLMC_LEGENDRE ? 0 : 1][plain ? 1 : 0][n_split == 64 ? 0 : (n_split == 96 ? 1 : 2)];
+            static int occ_split[2][2][4];   // [Legendre | monomial][plain][64 | 96 | 128 terms | second window]; 0 = not asked yet
+            int &cached = occ_split[bp.kind == MLMC_LEGENDRE ? 0 : 1][plain ? 1 : 0][t0 ? 3 : (n_split == 64 ? 0 : (n_split == 96 ? 1 : 2))];
             if (cached == 0)
-                if (int rc = split_dispatch(0, plain, bp, n_split, nullptr, 0, nullptr, nullptr, &cached)) return rc;
+                if (int rc = split_dispatch(0, plain, bp, n_split, t0, nullptr, 0, nullptr, nullptr, &cached)) return rc;
             per_cu = cached;
         } else if (!sparse_spline) {
             static int occ_cache[8][4][2][65];   // resident blocks per CU of (kind, pass class, plain, RT); 0 = not asked yet
@@ -999,7 +1014,7 @@ int flush_moments(mlmc_accum *a) {
                 hipLaunchKernelGGL(k_spline_accum<true>, dim3(total), dim3(ACC_THREADS), lds, st, bp, tab, R, a->d_partials, a->d_pcounts);
             MLMC_HIP_CHECK(hipGetLastError());
         } else if (split) {
-            if (int rc = split_dispatch(1, plain, bp, n_split, &tab, total, a->d_partials, a->d_pcounts, nullptr)) return rc;
+            if (int rc = split_dispatch(1, plain, bp, n_split, t0, &tab, total, a->d_partials, a->d_pcounts, nullptr)) return rc;
         } else if (int rc = accum_dispatch(1, plain, bp, rt_sel, &tab, total, t0, a->d_partials, a->d_pcounts, nullptr)) {
             return rc;
         }

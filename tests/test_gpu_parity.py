@@ -1138,9 +1138,9 @@ def test_adaptive_sampling_loop_matches_reference_trajectory(hip):
         assert np.allclose(means, case["means"], rtol=0, atol=1e-10) and np.allclose(vars_, case["vars"], rtol=1e-9, atol=1e-16)
 
 
-@pytest.mark.parametrize("R", [17, 32, 33, 40, 64])
+@pytest.mark.parametrize("R", [17, 32, 33, 40, 64, 65, 100, 128])
 def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
-    """Covariance WITH variances of 17..64 plain polynomial moments: the matrix cores accumulate the variance Grams only, the
+    """Covariance WITH variances of 17..128 plain polynomial moments: the matrix cores accumulate the variance Grams only, the
     means come from the level sums of the 2 R - 1 moments of the family (mlmc_hip.h, mlmc_accum_aux_kernel_time).  Against the
     oracle, and against the same library with all three Gram matrices on the matrix cores (MLMC_HIP_LINEARIZE=0): identical
     counts, bit-identical second-moment sums, means equal to rounding; host chunks, several chunks per level, a two-component
@@ -1151,7 +1151,7 @@ def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
     from mlmc_amd import Legendre, Monomial
     from mlmc_amd.engine import LevelAccumulator
     dom = (-3.7190164854556804, 3.7190164854556804)
-    levels = level_arrays([5301, 2500, 1777], [0.5, 0.07, 0.01], 1, 19)
+    levels = level_arrays([5301, 2500, 1777] if R <= 64 else [901, 500, 377], [0.5, 0.07, 0.01], 1, 19)
 
     def both(fn, lv, n_comp=1, device=False, split=False, min_n="0"):
         out = []
@@ -1192,10 +1192,10 @@ def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
             S = s.reshape(len(levels), R, R)
             assert S[0, 0, 0] == float(n[0]) and not S[1:, 0, 0].any()
         # chunks of 1767 | 3534, 833 | 1667, 592 | 1185 samples: direct and linearised contributions in one level
-        n, n_rm, s, sp = both(cls(R, dom), levels, device=True, split=True, min_n="1500")
+        n, n_rm, s, sp = both(cls(R, dom), levels, device=True, split=True, min_n="1500" if R <= 64 else "300")
         _check_against(n, n_rm, s, sp, ref)
     # two components: a sample is dropped when any component is masked
-    lv2 = level_arrays([2800, 1100], [0.3, 0.02], 2, 6)
+    lv2 = level_arrays([2800, 1100] if R <= 64 else [700, 300], [0.3, 0.02], 2, 6)
     b = onp.Basis(onp.LEGENDRE, R, dom)
     ref = onp.estimate_mean(to_chunks(lv2), lambda v: onp.covariance_rows(b, v))
     for device in (False, True):
@@ -1203,7 +1203,7 @@ def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
         _check_against(n, n_rm, s, sp, ref)
     # log=True: the keep / drop decision is the raw-value interval of the caller's basis, for both accumulators
     rng = np.random.default_rng(5)
-    x = rng.lognormal(mean=0.3, sigma=0.8, size=9011)
+    x = rng.lognormal(mean=0.3, sigma=0.8, size=9011 if R <= 64 else 1511)
     f1 = x * (1 + 0.01 * rng.normal(size=x.size))
     c1 = x * (1 + 0.03 * rng.normal(size=x.size))
     f1[::501] = -1.0

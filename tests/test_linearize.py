@@ -91,10 +91,11 @@ def _hip():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R", [65, 80, 96, 97, 127, 128])
+@pytest.mark.parametrize("R", [65, 80, 96, 97, 127, 128, 129, 199, 255, 256])
 def test_mean_only_split_kernel_65_to_128_terms(R):
-    """MOMENTS, mean only, 64 < R <= 128: one pass of k_moments_accum_split<..., SQ = false> (sp = NaN) against the
-    mean + variance passes of the same library and the oracle; ragged sizes, masks, level 0 only, monomials."""
+    """MOMENTS, mean only, 64 < R <= 256: one pass of k_moments_accum_split<..., SQ = false> (sp = NaN) per window of 128
+    terms (the second window's head first walks 128 recurrence steps without accumulating) against the mean + variance passes
+    of the same library and the oracle; ragged sizes, masks, level 0 only, monomials."""
     from mlmc_amd import Legendre, Monomial
     from mlmc_amd.engine import LevelAccumulator
     _hip()
@@ -115,7 +116,7 @@ def test_mean_only_split_kernel_65_to_128_terms(R):
             assert np.all(np.isnan(sp1)) and not np.any(np.isnan(sp2))
             scale = np.sqrt(np.abs(sp2) * np.maximum(n2[:, None], 1)) + 1e-300
             assert np.all(np.abs(s1 - s2) <= 1e-12 * np.maximum(np.abs(s2), scale)), (R, N, cls.__name__)
-            if cls is Legendre and N[0] > 100 and R in (65, 127):
+            if cls is Legendre and N[0] > 100 and R in (65, 127, 199):
                 # two components sharing one mask (k_mask + the general, non-PLAIN loop of the split kernel)
                 lv2 = level_arrays(N, steps[:len(N)], 2, 13)
                 pair = []
