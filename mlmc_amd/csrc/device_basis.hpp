@@ -79,6 +79,18 @@ struct TermGen {
             p2 = 0.0;  // sin(0 t) * w
         }
     }
+    // one step at an index >= 2 known only at run time: the term's coefficient comes from the caller (fetched ahead of the
+    // dependent chain), `j` has the parity of the index
+    __device__ __forceinline__ double skip(int j, double g) {
+        if (KIND == MLMC_LEGENDRE) {
+            const double q = __builtin_fma(x, p1, -(g * p2));
+            p2 = p1;
+            p1 = q;
+            return q;
+        } else {
+            return next(2 + (j & 1));
+        }
+    }
     // must be called with i = 0, 1, 2, ... in order
     __device__ __forceinline__ double next(int i) {
         if (i == 0) return p1;

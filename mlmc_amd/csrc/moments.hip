@@ -247,18 +247,52 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp,
         gf1.init(k1 ? tf1 : 0.0, w1, bp);
         if (PAIR) { gc0.init(k0 ? tc0 : 0.0, w0, bp); gc1.init(k1 ? tc1 : 0.0, w1, bp); }
 
-        if (T0C > 0) {   // second pass of 64 < R <= 128: advance the recurrences without accumulating, unrolled
+        if constexpr (T0C > 0) {   // second pass of 64 < R <= 128: advance the recurrences without accumulating, unrolled
 #pragma unroll
             for (int i = 0; i < T0C; ++i) {
                 gf0.next(i); gf1.next(i);
                 if (PAIR) { gc0.next(i); gc1.next(i); }
             }
-        } else if (T0C < 0) {   // R > 128: run-time term window (coefficients come through scalar loads)
-            for (int i = 0; i < t0; ++i) {
+        } else if constexpr (T0C < 0) {   // R > 128: run-time term window, t0 = 128, 192, ...: the first 128 steps with compile-time indices,
+                                // the rest in blocks of 64 whose coefficients are fetched ahead of the dependent steps (one
+                                // load per step inside the recurrence chain cost 20 x the step itself)
+#pragma unroll
+            for (int i = 0; i < 128; ++i) {
                 gf0.next(i); gf1.next(i);
                 if (PAIR) { gc0.next(i); gc1.next(i); }
             }
+            for (int b = 128; b < t0; b += 64) {
+                double gb[64];
+#pragma unroll
+                for (int j = 0; j < 64; ++j) gb[j] = KIND == MLMC_LEGENDRE ? kLegendreG.v[b + j] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    gf0.skip(j, gb[j]); gf1.skip(j, gb[j]);
+                    if (PAIR) { gc0.skip(j, gb[j]); gc1.skip(j, gb[j]); }
+                }
+            }
         }
+        if constexpr (T0C < 0) {
+            // run-time window: the coefficients of 16 terms are fetched (uniform address) ahead of their dependent steps
+            static_assert(RT % 16 == 0, "run-time term windows use 64-term tiles");
+#pragma unroll
+            for (int i0 = 0; i0 < RT; i0 += 16) {
+                double ga[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ga[j] = KIND == MLMC_LEGENDRE ? kLegendreG.v[t0 + i0 + j] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int i = i0 + j;
+                    double d0 = gf0.skip(i, ga[j]);
+                    double d1 = gf1.skip(i, ga[j]);
+                    if (PAIR) { d0 -= gc0.skip(i, ga[j]); d1 -= gc1.skip(i, ga[j]); }
+                    s[i] += d0;
+                    sp[i] = __builtin_fma(d0, d0, sp[i]);
+                    s[i] += d1;
+                    sp[i] = __builtin_fma(d1, d1, sp[i]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             double d0 = gf0.next(t0 + i);
@@ -268,6 +302,7 @@ __device__ __forceinline__ void accum_samples(const BasisParams &bp,
             sp[i] = __builtin_fma(d0, d0, sp[i]);
             s[i] += d1;
             sp[i] = __builtin_fma(d1, d1, sp[i]);
+        }
         }
         i0 = j0;
         i1 = j1;
