@@ -252,6 +252,9 @@ def roofline_block(mode, basis, R, pairs_per_step, singles_per_step, kt, steps, 
                               "bound": "valu_f64", "achieved": round(aux_flops / aux_s / 1e12, 3) if aux_s > 0 else 0.0,
                               "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(aux_flops / aux_s / 1e12 / FP64_VALU_PEAK_TFLOPS, 4) if aux_s > 0 else 0.0}}
+    pipe = pmc_fp64_pipe(config_key, kname)
+    if pipe is not None:
+        aux["fp64_pipe"] = pipe
     return dict(**aux, bound="mfma", achieved=round(ex_tf, 3), peak=peak, unit="TFLOP/s", frac=round(ex_tf / peak, 4),
                 **pmc_traffic(config_key, kname), kernel=kname, executed_mfma_flops_per_step=int(ex),
                 reference_form={"alg_flops_reference_form": int(flops), "achieved": round(tflops, 3), "frac": round(tflops / peak, 4),
@@ -785,6 +788,30 @@ def pmc_traffic(config_key, kname):
     same = value is not None and sha is not None and sha == csrc_sha()
     return {"traffic": value if same else None, "traffic_from_profile": value, "traffic_source": name,
             "traffic_profile_matches_build": bool(same)}
+
+
+def pmc_fp64_pipe(config_key, kname, n_simd=1024):
+    """Occupation of the shared fp64 pipe by the launches of `kname`, from the SQ counters of the committed PMC pass (separate
+    run, tools/collect_profiles.sh): matrix and vector fp64 instructions time-share ONE pipe per SIMD on gfx950
+    (tools/ubench_mfma_f64.hip), a v_mfma_f64_16x16x4_f64 holds it 64 cycles (SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA), any other
+    vector instruction of a 64-wide wave 4.  Fractions of GRBM_GUI_ACTIVE / 8 (XCDs), weighted over the matching kernels by
+    their dispatch counts.  None when the profile holds no SQ pass or was taken from other kernel sources."""
+    prof, name = _latest_pmc(config_key)
+    if prof is None or (prof.get("_meta") or {}).get("csrc_sha") != csrc_sha():
+        return None
+    mfma = valu = active = 0.0
+    for kn, e in prof.items():
+        if kn.startswith("_") or kname not in kn or "SQ_VALU_MFMA_BUSY_CYCLES_avg_per_dispatch" not in e or "[" in kn:
+            continue
+        d = e.get("dispatches_sq", 0)
+        mfma += e["SQ_VALU_MFMA_BUSY_CYCLES_avg_per_dispatch"] / n_simd * d
+        valu += 4.0 * (e["SQ_INSTS_VALU_avg_per_dispatch"] - e["SQ_INSTS_MFMA_avg_per_dispatch"]) / n_simd * d
+        active += e["GRBM_GUI_ACTIVE_avg_per_dispatch"] / 8.0 * d
+    if active <= 0:
+        return None
+    return {"mfma_frac": round(mfma / active, 4), "other_vector_frac": round(valu / active, 4), "busy_frac": round((mfma + valu) / active, 4),
+            "source": name, "note": "SQ counters of the committed profile of this build: cycles the one fp64 pipe of a SIMD is held by matrix "
+                                    "instructions (64 each) and by the other vector instructions (4 each), over GRBM_GUI_ACTIVE / 8"}
 
 
 def pmc_avg_bytes_per_dispatch(config_key, kname):

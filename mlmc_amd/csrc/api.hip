@@ -476,7 +476,7 @@ void mlmc_accum_destroy(mlmc_accum *a) {
     if (a->lin) mlmc_accum_destroy(a->lin);
     if (a->lin_basis) mlmc_basis_destroy(a->lin_basis);
     if (a->d_lin_prod) (void)hipFree(a->d_lin_prod);
-    void *ptrs[] = {a->d_state, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c, a->d_mask, a->d_out, a->d_vals_f, a->d_vals_c};
+    void *ptrs[] = {a->d_state, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c, a->d_mask, a->d_out, a->d_vals_f, a->d_vals_c, a->d_vals_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (a->h_out) (void)hipHostFree(a->h_out);
@@ -546,8 +546,8 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
                     rc = launch_cov_accum(a, level, m, f_m, c_m, d_mask, n, false, 1);
                 } else {
                     // difference Gram of more than 128 underlying moments: from materialised (scaled) values, chunk by chunk
-                    int64_t chunk = 1 << 18;
-                    while (chunk > 4096 && chunk * a->R > ((int64_t)1 << 25)) chunk >>= 1;
+                    int64_t chunk = 1 << 22;
+                    while (chunk > 4096 && chunk * a->R > ((int64_t)1 << 28)) chunk >>= 1;
                     const size_t need = sizeof(double) * (size_t)(n < chunk ? n : chunk) * a->R;
                     if (need > a->vals_cap) {
                         MLMC_HIP_CHECK(wait_stream(st));
@@ -572,8 +572,10 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             // covariance of TransformedMoments / of more than 128 moments: materialise the moment values chunk by chunk
             // (eval [+ matrix product]), then the MFMA covariance kernel reads them back, one 64 x 64 output block per launch
             const int R1 = a->Rout;
-            int64_t chunk = 1 << 18;
-            while (chunk > 4096 && chunk * R1 > ((int64_t)1 << 25)) chunk >>= 1;      // <= 256 MB of values per side
+            // <= 2 GB of values per side (of 288 GB): a chunk of 2^18 samples left every launch four batches per workgroup, and the
+            // 64 x 64-block launches of a 140-moment covariance spent their time on ramps and reductions (17 TFLOP/s)
+            int64_t chunk = 1 << 22;
+            while (chunk > 4096 && chunk * R1 > ((int64_t)1 << 28)) chunk >>= 1;
             const size_t need = sizeof(double) * (size_t)(n < chunk ? n : chunk) * R1;
             if (need > a->vals_cap) {
                 MLMC_HIP_CHECK(wait_stream(st));
@@ -585,11 +587,22 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
                 MLMC_HIP_CHECK(hipMalloc(&a->d_vals_c, need));
                 a->vals_cap = need;
             }
+            if (a->basis->out_size > 0) {      // workspace for the underlying values of one side (no allocation / sync per chunk)
+                const size_t need_tmp = sizeof(double) * (size_t)(n < chunk ? n : chunk) * a->R;
+                if (need_tmp > a->vals_tmp_cap) {
+                    MLMC_HIP_CHECK(wait_stream(st));
+                    if (a->d_vals_tmp) (void)hipFree(a->d_vals_tmp);
+                    a->d_vals_tmp = nullptr;
+                    a->vals_tmp_cap = 0;
+                    MLMC_HIP_CHECK(hipMalloc(&a->d_vals_tmp, need_tmp));
+                    a->vals_tmp_cap = need_tmp;
+                }
+            }
             rc = 0;
             for (int64_t off = 0; off < n && !rc; off += chunk) {
                 const int64_t m_n = (n - off < chunk) ? n - off : chunk;
-                rc = launch_eval(a->basis, f_m + off, m_n, R1, a->d_vals_f);
-                if (!rc && c_m) rc = launch_eval(a->basis, c_m + off, m_n, R1, a->d_vals_c);
+                rc = launch_eval(a->basis, f_m + off, m_n, R1, a->d_vals_f, a->d_vals_tmp);
+                if (!rc && c_m) rc = launch_eval(a->basis, c_m + off, m_n, R1, a->d_vals_c, a->d_vals_tmp);
                 if (!rc) rc = launch_cov_from_values(a, level, m, a->d_vals_f, c_m ? a->d_vals_c : nullptr,
                                                      d_mask ? d_mask + off : nullptr, m_n, count);
             }

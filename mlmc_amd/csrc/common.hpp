@@ -109,6 +109,7 @@ struct mlmc_accum {
     double *d_stage_f = nullptr, *d_stage_c = nullptr; size_t stage_cap = 0;
     uint8_t *d_mask = nullptr; size_t mask_cap = 0;
     double *d_vals_f = nullptr, *d_vals_c = nullptr; size_t vals_cap = 0;   // materialised moment values (COV of TransformedMoments)
+    double *d_vals_tmp = nullptr; size_t vals_tmp_cap = 0;                  // underlying values of a transformed basis, one side at a time
     void *d_out = nullptr;        // finalize outputs, one allocation: n[L] | n_rm[L] (int64) | n, n_rm as fp64 [2L] | s[L*K] | sp[L*K]
     size_t out_bytes = 0;
     void *h_out = nullptr;        // pinned host mirror of d_out (device-mapped)
