@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
     __shared__ double lds_fb[WIDE ? NT * STRIDE : 1];              // column window (off-diagonal blocks)
     __shared__ double lds_cb[(WIDE && PAIR) ? NT * STRIDE : 1];
     __shared__ int ldc[4][2];
+    __shared__ unsigned char keep_s[VALS ? BATCH : 1];
 
     // blockIdx.y = component of a vector quantity ([M][n] arrays, one mask for all): its own samples and partial rows
     fine += (int64_t)blockIdx.y * n;
@@ -222,6 +223,28 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
         int64_t idx = batch * BATCH + samp;
         if (idx < n) { xv = src[idx]; if (mask) mv = mask[idx]; }
     }
+    // VALS: the NT x BATCH tile(s) of values are loaded by the whole workgroup -- consecutive threads take consecutive terms of one
+    // sample row (coalesced segments of the row-major [n][R] values), all loads of a thread independent, one batch ahead.  (One
+    // evaluator lane per sample walking its row serially, as in the sample-evaluating form, left this phase latency bound: 18
+    // TFLOP/s where the same matrix work from registers runs at 52.)
+    constexpr int VSPP = 256 / NT;                       // samples per pass
+    constexpr int VNP = VALS ? BATCH / VSPP : 1;         // passes = values per thread, operand and window
+    const int vtt = threadIdx.x % NT, vss = threadIdx.x / NT;
+    const bool v_in_a = VALS && vals_ta + vtt < R, v_in_b = VALS && WIDE && vals_tb + vtt < R;
+    double pf[VNP][4];
+    auto vals_load = [&](int64_t b) {
+#pragma unroll
+        for (int p = 0; p < VNP; ++p) {
+            int64_t idx = b * BATCH + p * VSPP + vss;
+            if (idx >= n) idx = n - 1;                   // clamped, unconditional: the keep flags decide what counts
+            const int64_t ra = idx * (int64_t)R + (v_in_a ? vals_ta + vtt : 0), rb = idx * (int64_t)R + (v_in_b ? vals_tb + vtt : 0);
+            pf[p][0] = fine[ra];
+            pf[p][1] = PAIR ? coarse[ra] : 0.0;
+            pf[p][2] = WIDE ? fine[rb] : 0.0;
+            pf[p][3] = (WIDE && PAIR) ? coarse[rb] : 0.0;
+        }
+    };
+    if (VALS && batch < n_batches) vals_load(batch);
 #ifdef MLMC_PROF_COV
     unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
     const unsigned long long prof_t0 = prof_t, prof_r0 = __builtin_amdgcn_s_memrealtime();
@@ -230,21 +253,32 @@ __global__ __launch_bounds__(256, (BI != BJ && (!PAIR || MLMC_COV_WIDE_BATCH == 
     for (; batch < n_batches; batch += gridDim.x) {
         // ---------------- phase 1: moment values of this batch -> LDS ----------------
         if (VALS) {
-            if (evaluator) {
-                const int64_t idx = batch * BATCH + samp;
+            // (1) keep flags, one thread per sample (a masked value is NaN in every column: column 0 tells)
+            if (threadIdx.x < BATCH) {
+                const int64_t idx = batch * BATCH + threadIdx.x;
                 const bool valid = idx < n;
-                const double *__restrict__ row = src + idx * (int64_t)R;
                 bool keep = valid && (!mask || mask[idx] != 0);
-                if (keep) { const double v0 = row[0]; keep = !(v0 != v0); }      // a masked value is NaN in every column
-                if (PAIR) {
-                    const int other = __shfl_xor((int)keep, 32, 64);
-                    keep = keep && (other != 0);
-                }
-                if (!is_coarse) { n_keep += (int)keep; n_rm += (int)(valid && !keep); }
-                for (int i = 0; i < NT; ++i) dst[i * STRIDE + samp] = (keep && vals_ta + i < R) ? row[vals_ta + i] : 0.0;
-                if (WIDE)
-                    for (int i = 0; i < NT; ++i) dst_b[i * STRIDE + samp] = (keep && vals_tb + i < R) ? row[vals_tb + i] : 0.0;
+                if (keep) { const double v0 = fine[idx * (int64_t)R]; keep = !(v0 != v0); }
+                if (PAIR && keep) { const double c0 = coarse[idx * (int64_t)R]; keep = !(c0 != c0); }
+                n_keep += (int)keep;
+                n_rm += (int)(valid && !keep);
+                keep_s[threadIdx.x] = keep ? 1 : 0;
             }
+            __syncthreads();
+            // The tile of THIS batch was requested a batch ago (registers pf): it is dropped into LDS under the keep flags, then the
+            // next batch's loads are issued and fly during the matrix phase.
+#pragma unroll
+            for (int p = 0; p < VNP; ++p) {
+                const int sl = p * VSPP + vss;
+                const bool k = keep_s[sl] != 0;
+                lds_f[vtt * STRIDE + sl] = (k && v_in_a) ? pf[p][0] : 0.0;
+                if (PAIR) lds_c[vtt * STRIDE + sl] = (k && v_in_a) ? pf[p][1] : 0.0;
+                if (WIDE) {
+                    lds_fb[vtt * STRIDE + sl] = (k && v_in_b) ? pf[p][2] : 0.0;
+                    if (PAIR) lds_cb[vtt * STRIDE + sl] = (k && v_in_b) ? pf[p][3] : 0.0;
+                }
+            }
+            if (batch + gridDim.x < n_batches) vals_load(batch + gridDim.x);
         } else if (evaluator) {
             const int64_t idx = batch * BATCH + samp;
             const bool valid = idx < n;
