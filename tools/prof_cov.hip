@@ -131,6 +131,8 @@ int main(int argc, char **argv) {
     run<2, 2, false>("T=2 level 0, mean only", bp, f, c, n, 512);
     bp.size = 64;
     run<4, 0>("T=4 pair, mean+var", bp, f, c, n, 256 * COV_T4_WGS);
+    run<4, 3>("T=4 pair, variance only", bp, f, c, n, 256 * COV_T4_WGS);
+    run<4, 3, false>("T=4 level 0, variance only", bp, f, c, n, 256 * COV_T4_WGS);
     run<4, 2>("T=4 pair, mean only", bp, f, c, n, 256 * COV_T4_WGS);
     run<4, 0, false>("T=4 level 0, mean+var", bp, f, c, n, 256 * COV_T4_WGS);
     run<4, 2, false>("T=4 level 0, mean only", bp, f, c, n, 256 * COV_T4_WGS);
