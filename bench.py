@@ -504,6 +504,28 @@ def main():
         mcfg = dict(cfg, mode="moments", workload="configs[2] samples, stand-alone Legendre n_moments=64 mean+var estimate")
         blk = estimate_block(mcfg, data, fn, steps_h, ctx, 50, 10, 0.0, 3)
         out["moments_r64"] = dict(blk, config={"workload": mcfg["workload"], "levels": L, "samples_per_level_per_gpu": n_l, "n_moments": R})
+        if "aux_kernel" in head["roofline"]:
+            # the same estimate with ALL THREE Gram matrices on the matrix cores (the headline's form before the mean was
+            # linearised): more matrix work per sample at a higher matrix-pipe fraction, and a longer estimate
+            prev = os.environ.get("MLMC_HIP_LINEARIZE")
+            os.environ["MLMC_HIP_LINEARIZE"] = "0"
+            try:
+                blk = estimate_block(cfg, data, fn, steps_h, ctx, 10, 3, 0.0, None)
+            finally:
+                if prev is None:
+                    del os.environ["MLMC_HIP_LINEARIZE"]
+                else:
+                    os.environ["MLMC_HIP_LINEARIZE"] = prev
+            r3 = blk["roofline"]
+            out["three_gram_form"] = {
+                "ms_per_step": blk["ms_per_step"], "value": blk["value"], "unit": blk["unit"], "steps": blk["steps"], "warmup": blk["warmup"],
+                "roofline": {k: r3[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "executed_mfma_flops_per_step",
+                                                "avg_launch_ms", "launches_per_step")},
+                "note": "MLMC_HIP_LINEARIZE=0: covariance mean as a third Gram matrix (42 tiles per pair instead of 26 + the moments "
+                        "launch); same samples, same outputs"}
+            out["roofline"]["note"] = ("the matrix cores accumulate the two Gram matrices of the covariance's VARIANCE; its MEAN comes from "
+                                       "the aux_kernel launch (product linearisation).  three_gram_form in this line = the same estimate "
+                                       "with the mean's Gram matrix on the matrix cores too: higher matrix-pipe fraction, longer estimate")
     # ---- max-entropy PDF solve time (second half of BASELINE's metric), outside the timed region, rank 0 ------------
     if rank == 0:
         from mlmc_amd.engine import LevelAccumulator, level_stats

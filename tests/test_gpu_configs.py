@@ -231,3 +231,42 @@ def test_bench_multi_rank_default_is_config3_sharded(hip):
     assert rc["mean0"] == 1.0 and rc["var0"] == 0.0 and len(rc["n_estimated"]) == 5
     assert all(0 < r < 0.01 * total for r in rc["n_removed"])                          # both shards were counted
     assert abs(d["value"] - 5 * total * 64 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]   # whole-job samples x R / time
+
+
+def test_bench_default_line_carries_the_contract(hip):
+    """`python bench.py` (N = 1 defaults apart from K / W): ONE JSON line with the driver's keys, BASELINE configs[2] as the
+    workload, `roofline` (bound / achieved / peak / unit / frac / traffic) of the dominant kernel with the auxiliary moments
+    launch and the three-Gram form beside it, `cpu_baseline` on a bounded sample, the in-run parity gate green."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2"], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["n_moments"] == 64 and d["config"]["samples_per_level_per_gpu"] == 10_000_000
+    assert abs(d["value"] - 5 * 10_000_000 * 64 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.5 < r["frac"] < 1.0 and "traffic" in r
+    assert r["executed_mfma_flops_per_step"] == 512 * (26 * 4 + 10) * 10_000_000
+    assert r["aux_kernel"]["launches_per_step"] == 1 and 0 < r["aux_kernel"]["ms_per_step"] < 0.3 * d["ms_per_step"]
+    if r["traffic"] is not None:                                        # a profile of this very build is committed
+        assert r["traffic_profile_matches_build"] and 0.5 < r["fp64_pipe"]["busy_frac"] <= 1.0
+    t3 = d["three_gram_form"]
+    assert t3["roofline"]["executed_mfma_flops_per_step"] == 512 * (42 * 4 + 20) * 10_000_000
+    assert t3["ms_per_step"] > d["ms_per_step"] and t3["roofline"]["frac"] > r["frac"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == d["unit"] and cb["value"] > 0 and "sample" in cb
+    assert d["parity"]["ok"] and d["parity"]["counts_bit_exact"]
+    assert d["result_check"]["mean0"] == 1.0 and d["result_check"]["var0"] == 0.0
+    for k in ("moments_r64", "configs1", "north_star", "pdf_solve", "h2d_inclusive"):
+        assert k in d, k
