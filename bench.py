@@ -209,10 +209,12 @@ def roofline_block(mode, basis, R, pairs_per_step, singles_per_step, kt, steps, 
     (algorithmic bytes / average launch duration) ride beside it under "hbm".
     Covariance: `achieved` / `frac` count the flops the matrix pipe EXECUTES -- 512 per 16 x 16 tile and sample, the tiles
     of the symmetric Gram matrices once (SURVEY 8(d) allows symmetric halves), as reported by the library
-    (mlmc_accum_kernel_flops) -- a physical fraction of the fp64 matrix peak.  At 33..64 polynomial moments the matrix
-    cores compute the two Gram matrices of the VARIANCE only (R = 64: 16 + 10 = 26 tiles per pair, 10 per level-0 sample;
-    with the mean's Gram matrix it was 42 / 20): the mean of the covariance comes from one mean-only launch of the moments
-    kernel over 2 R - 1 terms (product linearisation, mlmc_hip.h), reported beside it under "aux_kernel".  The
+    (mlmc_accum_kernel_flops) -- a physical fraction of the fp64 matrix peak.  At 17..128 polynomial moments the matrix
+    cores compute the two Gram matrices of the VARIANCE only, and up to 64 moments only at the pair levels (R = 64: 16 + 10 =
+    26 tiles per pair; with the mean's Gram matrix it was 42, and 20 per level-0 sample): the mean of the covariance comes
+    from one mean-only launch of the moments kernel over 2 R - 1 terms, and level 0 -- one value per sample, so its second
+    moments linearise as well -- from two launches over 4 R - 3 terms (product linearisation, mlmc_hip.h), reported beside
+    it under "aux_kernel".  The
     reference-form count (6 R^2 + 14 R per pair: every entry of three R x R matrices) rides beside it under
     "reference_form"; it exceeds what any kernel that uses the symmetry has to execute, so its fraction can pass 1."""
     k_ms, launches, k_bytes, mfma_flops = kt[:4]
@@ -243,11 +245,14 @@ def roofline_block(mode, basis, R, pairs_per_step, singles_per_step, kt, steps, 
     if aux_launches:
         # the covariance MEAN comes from the level sums of the 2 R - 1 moments of the product linearisation: one mean-only
         # launch of the moments kernel per estimate beside the matrix-core launches (which then execute G1, G2 only)
+        # ... and at level 0 (<= 64 moments) the second moments too, from 4 R - 3 moments in two windows: no matrix pass there
         K = 2 * R - 1
+        K0 = 4 * R - 3 if R <= 64 else K
         # flops per term: recurrence (multiply + FMA = 3) per value, difference 1, sum 1 -> 8 per pair, 4 per level-0 sample
-        aux_flops = (8 * K) * pairs_per_step + (4 * K) * singles_per_step
+        aux_flops = (8 * K) * pairs_per_step + (4 * K0) * singles_per_step
         aux_s = aux_ms / 1e3 / max(steps, 1)
-        aux = {"aux_kernel": {"kernel": "k_moments_accum_split (mean-only, %d terms: product linearisation of the covariance mean)" % K,
+        aux = {"aux_kernel": {"kernel": "k_moments_accum_split (mean-only: %d terms over the pair levels = product linearisation of the "
+                                        "covariance mean; %d terms at level 0 = mean and second moments there)" % (K, K0),
                               "ms_per_step": round(1e3 * aux_s, 4), "launches_per_step": aux_launches // max(steps, 1),
                               "bound": "valu_f64", "achieved": round(aux_flops / aux_s / 1e12, 3) if aux_s > 0 else 0.0,
                               "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -521,11 +526,12 @@ def main():
                 "ms_per_step": blk["ms_per_step"], "value": blk["value"], "unit": blk["unit"], "steps": blk["steps"], "warmup": blk["warmup"],
                 "roofline": {k: r3[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "executed_mfma_flops_per_step",
                                                 "avg_launch_ms", "launches_per_step")},
-                "note": "MLMC_HIP_LINEARIZE=0: covariance mean as a third Gram matrix (42 tiles per pair instead of 26 + the moments "
-                        "launch); same samples, same outputs"}
-            out["roofline"]["note"] = ("the matrix cores accumulate the two Gram matrices of the covariance's VARIANCE; its MEAN comes from "
-                                       "the aux_kernel launch (product linearisation).  three_gram_form in this line = the same estimate "
-                                       "with the mean's Gram matrix on the matrix cores too: higher matrix-pipe fraction, longer estimate")
+                "note": "MLMC_HIP_LINEARIZE=0: covariance mean as a third Gram matrix and level 0 on the matrix cores (42 tiles per pair, "
+                        "20 per level-0 sample, instead of 26 / 0 + the moments launches); same samples, same outputs"}
+            out["roofline"]["note"] = ("the matrix cores accumulate the two Gram matrices of the covariance's VARIANCE at the pair levels; its "
+                                       "MEAN and all of level 0 come from the aux_kernel launches (product linearisation).  three_gram_form "
+                                       "in this line = the same estimate with everything on the matrix cores: higher matrix-pipe fraction, "
+                                       "longer estimate")
     # ---- max-entropy PDF solve time (second half of BASELINE's metric), outside the timed region, rank 0 ------------
     if rank == 0:
         from mlmc_amd.engine import LevelAccumulator, level_stats

@@ -160,9 +160,13 @@ int mlmc_accum_kernel_flops(mlmc_accum *a, int64_t *mfma_flops);
  * of the same family through the product linearisation phi_i phi_j = sum_k c_ijk phi_k (Legendre: Adams' formula, non-negative
  * coefficients that sum to one) -- one mean-only pass of the moments kernel over the same chunks with the same keep / drop
  * decisions, contracted on the device at finalize.  Same outputs, same counts; the means agree with the direct sums to rounding
- * (a convex combination of sums instead of sums of products).  MLMC_HIP_LINEARIZE=0 in the environment keeps all three Gram
- * matrices on the matrix cores.  This call reports the HIP-event time, launches and algorithmic bytes of that auxiliary
- * moments pass (zeros when the accumulator has none), like mlmc_accum_kernel_time does for the matrix-core launches. */
+ * (a convex combination of sums instead of sums of products).  A large chunk WITHOUT coarse values (level 0) of <= 64 such
+ * moments needs no matrix pass at all: with one value per sample the second moments linearise too, (phi_i phi_j)^2 =
+ * sum_k c2_ijk phi_k with k < 4 R - 3, so the level sums of 4 R - 3 moments (two windows of the same mean-only kernel, which
+ * then also does the counting) give both sum f_i f_j and sum (f_i f_j)^2; MLMC_HIP_LINEARIZE_LEVEL0=0 keeps level 0 on the matrix
+ * cores.  MLMC_HIP_LINEARIZE=0 in the environment keeps all three Gram matrices of every chunk on the matrix cores.  This call
+ * reports the HIP-event time, launches and algorithmic bytes of the auxiliary moments passes (zeros when the accumulator has
+ * none), like mlmc_accum_kernel_time does for the matrix-core launches. */
 int mlmc_accum_aux_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes);
 
 /* ---- maximum-entropy density (mlmc/tool/simple_distribution.py:9-327) ------------------ */

@@ -6,6 +6,7 @@
 
 #include "common.hpp"
 #include <algorithm>
+#include <map>
 
 namespace mlmc {
 
@@ -152,6 +153,78 @@ bool product_table(int kind, int R, std::vector<double> &out) {
                 ratio = ratio * (sk / (2 * sk - 1));          // A(sk - 1) / A(sk)
                 ratio = ratio * ((s + 1) / (2 * s + 1));      // A(s) / A(s + 1)
                 c = c * ratio;
+            }
+        }
+    return true;
+}
+
+// (phi_i phi_j)^2 = sum_k c2_ijk phi_k, k < 4 R - 3: the level-0 second moments of the covariance from level sums of moments.
+// Legendre: the coefficients are (2k + 1) / 2 * int P_k (P_i P_j)^2, a polynomial of degree <= 8 R - 8 integrated exactly by a
+// Gauss-Legendre rule of 4 R points, nodes and weights by Newton's iteration, everything in extended precision and rounded
+// once; odd k and k > 2 (i + j) are exact zeros; non-negative, rows sum to one.  Monomials: t^(2 (i + j)).
+bool square_product_table(int kind, int R, std::vector<double> &out) {
+    if (kind != MLMC_LEGENDRE && kind != MLMC_MONOMIAL) return false;
+    const int K = 4 * R - 3;
+    const size_t RR = (size_t)R * R;
+    out.assign((size_t)K * RR, 0.0);
+    if (kind == MLMC_MONOMIAL) {
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < R; ++j) out[(size_t)(2 * (i + j)) * RR + (size_t)i * R + j] = 1.0;
+        return true;
+    }
+    typedef long double ld;
+    const int Q = 4 * R;
+    const ld pi = 3.14159265358979323846264338327950288L;
+    std::vector<ld> x(Q), w(Q), P((size_t)K * Q);
+    for (int q = 0; q < Q; ++q) {
+        ld t = std::cos(pi * ((ld)q + 0.75L) / ((ld)Q + 0.5L)), dp = 1.0L;
+        for (int it = 0; it < 100; ++it) {
+            ld p0 = 1.0L, p1 = t;
+            for (int k = 2; k <= Q; ++k) {
+                const ld p2 = ((2 * k - 1) * t * p1 - (k - 1) * p0) / k;
+                p0 = p1;
+                p1 = p2;
+            }
+            dp = Q * (t * p1 - p0) / (t * t - 1.0L);
+            const ld dt = p1 / dp;
+            t -= dt;
+            if (std::fabs(dt) < 1e-20L) break;
+        }
+        {   // derivative at the converged node for the weight
+            ld p0 = 1.0L, p1 = t;
+            for (int k = 2; k <= Q; ++k) {
+                const ld p2 = ((2 * k - 1) * t * p1 - (k - 1) * p0) / k;
+                p0 = p1;
+                p1 = p2;
+            }
+            dp = Q * (t * p1 - p0) / (t * t - 1.0L);
+        }
+        x[q] = t;
+        w[q] = 2.0L / ((1.0L - t * t) * dp * dp);
+        ld p0 = 1.0L, p1 = t;
+        P[(size_t)0 * Q + q] = 1.0L;
+        if (K > 1) P[(size_t)1 * Q + q] = t;
+        for (int k = 2; k < K; ++k) {
+            const ld p2 = ((2 * k - 1) * t * p1 - (k - 1) * p0) / k;
+            p0 = p1;
+            p1 = p2;
+            P[(size_t)k * Q + q] = p2;
+        }
+    }
+    std::vector<ld> sq(Q);
+    for (int i = 0; i < R; ++i)
+        for (int j = i; j < R; ++j) {
+            for (int q = 0; q < Q; ++q) {
+                const ld u = P[(size_t)i * Q + q] * P[(size_t)j * Q + q];
+                sq[q] = w[q] * u * u;
+            }
+            for (int k = 0; k <= 2 * (i + j); k += 2) {
+                ld acc = 0.0L;
+                const ld *Pk = &P[(size_t)k * Q];
+                for (int q = 0; q < Q; ++q) acc += sq[q] * Pk[q];
+                const double c = (double)(acc * (2 * k + 1) / 2);
+                out[(size_t)k * RR + (size_t)i * R + j] = c;
+                out[(size_t)k * RR + (size_t)j * R + i] = c;
             }
         }
     return true;
@@ -447,6 +520,26 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
             if (e == hipSuccess) e = hipMemcpy(a->d_lin_prod, table.data(), sizeof(double) * table.size(), hipMemcpyHostToDevice);
             if (e != hipSuccess) rc = fail(std::string("mlmc_accum_create: ") + hipGetErrorString(e));
         }
+        // level 0 without the matrix cores (<= 64 moments: the 4 R - 3 extended terms fit the two windows of the mean-only kernel)
+        const char *lin0_env = std::getenv("MLMC_HIP_LINEARIZE_LEVEL0");
+        if (!rc && a->R <= 64 && !(lin0_env && lin0_env[0] == '0')) {
+            // the table costs ~1 s of host time at R = 64: built once per (family, size)
+            static std::map<std::pair<int, int>, std::vector<double>> cache;
+            std::vector<double> &t2 = cache[std::make_pair((int)b->p.kind, a->R)];
+            if (t2.empty()) square_product_table(b->p.kind, a->R, t2);
+            d.size = 4 * a->R - 3;
+            rc = mlmc_basis_create(&d, &a->lin0_basis);
+            if (!rc) rc = mlmc_accum_create(a->lin0_basis, n_levels, MLMC_MODE_MOMENTS | MLMC_MODE_MEAN_ONLY, n_comp, &a->lin0);
+            if (!rc) {
+                a->lin0_basis->p.x_lo = b->p.x_lo;
+                a->lin0_basis->p.x_hi = b->p.x_hi;
+                a->lin0->host_outputs = false;
+                a->lin0_K = d.size;
+                hipError_t e = hipMalloc(&a->d_lin0_prod, sizeof(double) * t2.size());
+                if (e == hipSuccess) e = hipMemcpy(a->d_lin0_prod, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice);
+                if (e != hipSuccess) rc = fail(std::string("mlmc_accum_create: ") + hipGetErrorString(e));
+            }
+        }
         if (rc) {
             mlmc_accum_destroy(a);
             return rc;
@@ -464,7 +557,9 @@ int mlmc_accum_reset(mlmc_accum *a) {
     a->pending.clear();
     std::fill(a->level_flushed.begin(), a->level_flushed.end(), 0);
     MLMC_HIP_CHECK(hipMemsetAsync(a->d_state, 0, a->state_bytes, st));
-    a->lin_used = false;
+    a->lin_used = a->lin0_used = false;
+    if (a->lin0)
+        if (int rc = mlmc_accum_reset(a->lin0)) return rc;
     if (a->lin) return mlmc_accum_reset(a->lin);
     return 0;
 }
@@ -475,6 +570,9 @@ void mlmc_accum_destroy(mlmc_accum *a) {
     if (rt().ready) (void)wait_stream(rt().stream);
     if (a->lin) mlmc_accum_destroy(a->lin);
     if (a->lin_basis) mlmc_basis_destroy(a->lin_basis);
+    if (a->lin0) mlmc_accum_destroy(a->lin0);
+    if (a->lin0_basis) mlmc_basis_destroy(a->lin0_basis);
+    if (a->d_lin0_prod) (void)hipFree(a->d_lin0_prod);
     if (a->d_lin_prod) (void)hipFree(a->d_lin_prod);
     void *ptrs[] = {a->d_state, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c, a->d_mask, a->d_out, a->d_vals_f, a->d_vals_c, a->d_vals_tmp};
     for (void *p : ptrs)
@@ -608,6 +706,16 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             }
         } else {
             // all components of a vector quantity in one launch (grid.y = component; they share the mask)
+            // level 0 (one value per sample) of <= 64 moments: mean AND second moments from the level sums of 4 R - 3 moments --
+            // no matrix pass; the moments kernel does the counting
+            const bool use_lin0 = a->lin0 && !d_c && n >= a->lin_min_n;
+            if (use_lin0) {
+                a->lin0_used = true;
+                rc = launch_moments_accum(a->lin0, level, m, f_m, nullptr, d_mask, n, count_in_kernel && m == 0,
+                                          mem_kind == MLMC_DEVICE || a->n_comp > 1);
+                if (rc) return rc;
+                continue;
+            }
             const bool use_lin = a->lin && n >= a->lin_min_n;
             rc = m == 0 ? launch_cov_accum(a, level, 0, d_f, d_c, d_mask, n, count_in_kernel, a->mean_only ? 2 : (use_lin ? 3 : 0), a->n_comp) : 0;
             // the extended moments of the linearised mean over the same chunk (same mask; the covariance kernel counts);
@@ -624,6 +732,8 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
         if (int rc = flush_moments(a)) return rc;
     if (a->lin && (mem_kind == MLMC_HOST || a->n_comp > 1))
         if (int rc = flush_moments(a->lin)) return rc;
+    if (a->lin0 && (mem_kind == MLMC_HOST || a->n_comp > 1))
+        if (int rc = flush_moments(a->lin0)) return rc;
     return 0;
 }
 
@@ -745,10 +855,15 @@ int mlmc_accum_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t
 int mlmc_accum_aux_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes) {
     MLMC_API_GUARD;
     if (!a) return fail("mlmc_accum_aux_kernel_time: null argument");
-    if (a->lin) return mlmc_accum_kernel_time(a->lin, ms, launches, alg_bytes);
-    if (ms) *ms = 0.0;
-    if (launches) *launches = 0;
-    if (alg_bytes) *alg_bytes = 0;
+    double t = 0.0, t0 = 0.0;
+    int64_t l = 0, l0 = 0, b = 0, b0 = 0;
+    if (a->lin)
+        if (int rc = mlmc_accum_kernel_time(a->lin, &t, &l, &b)) return rc;
+    if (a->lin0)
+        if (int rc = mlmc_accum_kernel_time(a->lin0, &t0, &l0, &b0)) return rc;
+    if (ms) *ms = t + t0;
+    if (launches) *launches = l + l0;
+    if (alg_bytes) *alg_bytes = b + b0;
     return 0;
 }
 

@@ -133,6 +133,14 @@ struct mlmc_accum {
     mlmc_basis *lin_basis = nullptr;      // the family's member of size lin_K = 2 R - 1
     double *d_lin_prod = nullptr;         // [lin_K][R * R]: c_ijk, k-major
     int lin_K = 0;
+    // ... and at LEVEL 0 (one value per sample) the variance linearises as well: (phi_i phi_j)^2 = sum_k c2_ijk phi_k, k < 4 R - 3, so a
+    // large level-0 chunk of <= 64 moments needs no matrix pass at all -- a second inner accumulator over the size-(4 R - 3) member
+    // (two windows of the mean-only kernel) gives sum f_i f_j (its first 2 R - 1 sums) and sum (f_i f_j)^2
+    mlmc_accum *lin0 = nullptr;
+    mlmc_basis *lin0_basis = nullptr;
+    double *d_lin0_prod = nullptr;        // [lin0_K][R * R]: c2_ijk, k-major
+    int lin0_K = 0;
+    bool lin0_used = false;
     int64_t lin_min_n = 0;                // chunks with fewer samples keep all three Gram matrices on the matrix cores (the
                                           // extra launches of the auxiliary pass cost more than they save); sums are additive
     bool lin_used = false;                // a chunk of this estimate went the linearised way
@@ -154,6 +162,8 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
 int launch_cov_finalize(mlmc_accum *a);
 // c_ijk of the product linearisation, k-major [2 R - 1][R * R]; false: the family has none here
 bool product_table(int kind, int R, std::vector<double> &out);
+// c2_ijk of (phi_i phi_j)^2 = sum_k c2_ijk phi_k, k-major [4 R - 3][R * R]
+bool square_product_table(int kind, int R, std::vector<double> &out);
 int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_vf, const double *d_vc, const uint8_t *d_mask,
                            int64_t n, bool count, int gram_mode = 0);
 int ensure(void **p, size_t *cap, size_t bytes);

@@ -1229,14 +1229,17 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
 __global__ void k_cov_finalize(const double *__restrict__ totals, const double *__restrict__ scale_c, int R, int RP,
                                int64_t int_width, double *__restrict__ out_s, double *__restrict__ out_sp,
                                const int64_t *__restrict__ counts, int n_levels, int64_t *__restrict__ out_n,
-                               double *__restrict__ out_nd, int mean_only) {
+                               double *__restrict__ out_nd, int mean_only, const int64_t *__restrict__ counts2) {
     const int lc = blockIdx.y;
     if (lc == 0 && blockIdx.x == 0)
         for (int l = threadIdx.x; l < n_levels; l += blockDim.x) {
-            out_n[l] = counts[2 * l];
-            out_n[n_levels + l] = counts[2 * l + 1];
-            out_nd[l] = (double)counts[2 * l];               // exact below 2^53: lets one fp64 all-reduce carry the counts
-            out_nd[n_levels + l] = (double)counts[2 * l + 1];
+            // counts2: the chunks that never saw a covariance kernel (level 0 through the linearised second moments) were counted
+            // by the moments kernel of the inner accumulator
+            const int64_t kept = counts[2 * l] + (counts2 ? counts2[2 * l] : 0), removed = counts[2 * l + 1] + (counts2 ? counts2[2 * l + 1] : 0);
+            out_n[l] = kept;
+            out_n[n_levels + l] = removed;
+            out_nd[l] = (double)kept;                        // exact below 2^53: lets one fp64 all-reduce carry the counts
+            out_nd[n_levels + l] = (double)removed;
         }
     const double *G0 = totals + (int64_t)lc * int_width;
     const double *G1 = G0 + (int64_t)RP * RP;
@@ -1271,14 +1274,27 @@ int launch_cov_finalize(mlmc_accum *a) {
     if (a->lin && a->lin_used) {
         if (int rc = flush_moments(a->lin)) return rc;
     }
+    const bool lin0 = a->lin0 && a->lin0_used;
+    if (lin0) {
+        if (int rc = flush_moments(a->lin0)) return rc;
+    }
     const int n_lc = a->n_levels * a->n_comp;
     const bool vals = a->cov_from_values;              // TransformedMoments / more than 128 moments: accumulated from true values
     const int R = vals ? a->Rout : a->R;
     hipLaunchKernelGGL(k_cov_finalize, dim3((R * R + 255) / 256, n_lc), dim3(256), 0, rt().stream, a->d_totals,
                        vals ? (const double *)nullptr : a->basis->d_scale, R,
                        a->RP, a->int_width, a->d_out_s, a->d_out_sp, a->d_counts, a->n_levels, a->d_out_n, a->d_out_nd,
-                       a->mean_only ? 1 : 0);
+                       a->mean_only ? 1 : 0, lin0 ? a->lin0->d_counts : (const int64_t *)nullptr);
     MLMC_HIP_CHECK(hipGetLastError());
+    if (lin0) {
+        // level-0 chunks that went without a matrix pass: sum f_i f_j from the first 2 R - 1 extended sums, sum (f_i f_j)^2 from all
+        // 4 R - 3 (at level 0 the finalize formula 1/4 (G1 + G1^T + 2 G2) is this very sum: both kinds of chunk add up)
+        hipLaunchKernelGGL(k_cov_lin_mean, dim3((R * R + 255) / 256, n_lc), dim3(256), sizeof(double) * a->lin_K, rt().stream,
+                           a->d_lin_prod, a->lin0->d_totals, a->lin0_basis->d_scale, R, a->lin_K, a->lin0->int_width, a->d_out_s);
+        hipLaunchKernelGGL(k_cov_lin_mean, dim3((R * R + 255) / 256, n_lc), dim3(256), sizeof(double) * a->lin0_K, rt().stream,
+                           a->d_lin0_prod, a->lin0->d_totals, a->lin0_basis->d_scale, R, a->lin0_K, a->lin0->int_width, a->d_out_sp);
+        MLMC_HIP_CHECK(hipGetLastError());
+    }
     if (a->lin && a->lin_used) {       // chunks without G0 (gram_mode 3): their share of the means comes from the extended moments
         hipLaunchKernelGGL(k_cov_lin_mean, dim3((R * R + 255) / 256, n_lc), dim3(256), sizeof(double) * a->lin_K, rt().stream,
                            a->d_lin_prod, a->lin->d_totals, a->lin_basis->d_scale, R, a->lin_K, a->lin->int_width, a->d_out_s);

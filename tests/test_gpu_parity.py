@@ -1176,7 +1176,15 @@ def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
         monkeypatch.delenv("MLMC_HIP_LINEARIZE_MIN_N")
         (n, n_rm, s, sp), (n0, n_rm0, s0, sp0) = out
         assert np.array_equal(n, n0) and np.array_equal(n_rm, n_rm0)
-        assert np.array_equal(sp, sp0)                                    # the same instructions in the same order
+        # pair levels: the same matrix instructions in the same order; levels without coarse values (<= 64 moments): the second
+        # moments come from the level sums of 4 R - 3 moments (a convex combination of sums instead of sums of squares)
+        pair = np.array([c is not None for _, c in lv])
+        if fn.size > 64:
+            assert np.array_equal(sp, sp0)
+        else:
+            assert np.array_equal(sp[pair], sp0[pair])
+            big = np.max(np.abs(sp0[~pair]), axis=1, keepdims=True)
+            assert np.max(np.abs(sp[~pair] - sp0[~pair]) / np.maximum(np.abs(sp0[~pair]), 1e-3 * big)) < 1e-11
         scale = np.sqrt(np.abs(sp0) * n[:, None]) + 1e-300
         assert np.max(np.abs(s - s0) / scale) < 1e-12, np.max(np.abs(s - s0) / scale)
         return n, n_rm, s, sp
