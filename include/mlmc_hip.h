@@ -29,9 +29,9 @@
 extern "C" {
 #endif
 
-#define MLMC_ABI_VERSION 5   /* 2: strides in mlmc_expr_eval, chaining flags, mlmc_accum_estimate_packed; 3: mlmc_wait_event;
+#define MLMC_ABI_VERSION 6   /* 2: strides in mlmc_expr_eval, chaining flags, mlmc_accum_estimate_packed; 3: mlmc_wait_event;
                               * 4: x_lo / x_hi in mlmc_basis_desc, mlmc_expr_state, mlmc_accum_kernel_flops;
-                              * 5: mlmc_accum_aux_kernel_time */
+                              * 5: mlmc_accum_aux_kernel_time; 6: mlmc_linearization_table */
 
 /* basis kinds -- mlmc/moments.py: Legendre :174-229, Monomial :111-130, Fourier :133-171;
  * IDENTITY = the quantity itself (estimate_mean of a plain quantity, quantity_estimate.py:22-80);
@@ -168,6 +168,11 @@ int mlmc_accum_kernel_flops(mlmc_accum *a, int64_t *mfma_flops);
  * reports the HIP-event time, launches and algorithmic bytes of the auxiliary moments passes (zeros when the accumulator has
  * none), like mlmc_accum_kernel_time does for the matrix-core launches. */
 int mlmc_accum_aux_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int64_t *alg_bytes);
+/* The coefficient tables of those linearisations, as the accumulators use them (host arithmetic only: needs no device, e.g.
+ * for checking them against exact rational values): squares == 0: phi_i phi_j = sum_k c_ijk phi_k, K = 2 R - 1;
+ * squares != 0: (phi_i phi_j)^2 = sum_k c2_ijk phi_k, K = 4 R - 3.  out [K][R * R] (k-major), out_len >= K * R * R.
+ * kind: MLMC_LEGENDRE or MLMC_MONOMIAL, 1 <= R <= 128 (squares: R <= 64). */
+int mlmc_linearization_table(int32_t kind, int32_t R, int32_t squares, double *out, int64_t out_len);
 
 /* ---- maximum-entropy density (mlmc/tool/simple_distribution.py:9-327) ------------------ */
 typedef struct {

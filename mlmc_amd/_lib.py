@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MLMC_HIP_LIB", os.path.join(_HERE, "libmlmc_hip.so"))   # env override: development builds
 
-ABI_VERSION = 5      # MLMC_ABI_VERSION of include/mlmc_hip.h
+ABI_VERSION = 6      # MLMC_ABI_VERSION of include/mlmc_hip.h
 LEGENDRE, MONOMIAL, FOURIER, IDENTITY, SPLINE = 0, 1, 2, 3, 4
 MODE_MOMENTS, MODE_COV = 0, 1
 MODE_MEAN_ONLY = 0x100
@@ -70,6 +70,7 @@ SIGNATURES = {
     "mlmc_accum_kernel_time": (C.c_int, [_vp, _dp, _ip, _ip]),
     "mlmc_accum_kernel_flops": (C.c_int, [_vp, _ip]),
     "mlmc_accum_aux_kernel_time": (C.c_int, [_vp, _dp, _ip, _ip]),
+    "mlmc_linearization_table": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int64]),
     "mlmc_percentiles": (C.c_int, [_vp, C.c_int64, _vp, C.c_int32, _vp, _ip, C.c_int]),
     "mlmc_maxent_solve": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.POINTER(MaxentOpts), _vp,
                                     C.c_int32, _vp, _vp, _vp, C.POINTER(MaxentInfo)]),

@@ -867,6 +867,19 @@ int mlmc_accum_aux_kernel_time(mlmc_accum *a, double *ms, int64_t *launches, int
     return 0;
 }
 
+int mlmc_linearization_table(int32_t kind, int32_t R, int32_t squares, double *out, int64_t out_len) {
+    if (!out) return fail("mlmc_linearization_table: null argument");
+    if (kind != MLMC_LEGENDRE && kind != MLMC_MONOMIAL) return fail("mlmc_linearization_table: Legendre or monomial moments");
+    if (R < 1 || R > (squares ? 64 : 128)) return fail("mlmc_linearization_table: size out of range");
+    const int64_t K = squares ? 4 * (int64_t)R - 3 : 2 * (int64_t)R - 1;
+    if (out_len < K * R * R) return fail("mlmc_linearization_table: output too small");
+    std::vector<double> t;
+    if (squares) square_product_table(kind, R, t);
+    else product_table(kind, R, t);
+    std::memcpy(out, t.data(), sizeof(double) * t.size());
+    return 0;
+}
+
 int mlmc_accum_kernel_flops(mlmc_accum *a, int64_t *mfma_flops) {
     MLMC_API_GUARD;
     if (!a) return fail("mlmc_accum_kernel_flops: null argument");

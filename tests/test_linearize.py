@@ -252,3 +252,82 @@ def test_linearised_covariance_mean_of_a_vector_quantity(monkeypatch):
             assert lin.l_means.shape == full.l_means.shape and lin.mean.shape == full.mean.shape
             rms = np.sqrt(np.maximum(full.l_vars, 0) + full.l_means ** 2)
             assert np.all(np.abs(lin.l_means - full.l_means) <= 1e-10 * np.maximum(np.abs(full.l_means), rms) + 1e-300), (R, at_bottom)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The tables the LIBRARY builds for its own linearisations (covariance with variances: mean from 2 R - 1 moments, level 0
+# from 4 R - 3): host arithmetic behind the C ABI, checked here without a GPU.
+def _lib_table(kind, R, squares):
+    from mlmc_amd import _lib
+    K = 4 * R - 3 if squares else 2 * R - 1
+    out = np.empty(K * R * R)
+    _lib.check(_lib.load().mlmc_linearization_table(kind, R, int(squares), _lib.ptr(out), out.size))
+    return out.reshape(K, R, R)
+
+
+def _exact_legendre_products(R):
+    """c_ijk as Fractions by Adams' formula with exact factorial ratios (small R only)."""
+    from fractions import Fraction
+    from math import factorial
+
+    def A(n):                                        # (2n - 1)!! / n! = (2n)! / (2^n n!^2)
+        return Fraction(factorial(2 * n), 2 ** n * factorial(n) ** 2)
+    c = {}
+    for i in range(R):
+        for j in range(R):
+            for k in range(abs(i - j), i + j + 1, 2):
+                s = (i + j + k) // 2
+                c[i, j, k] = Fraction(2 * k + 1, 2 * s + 1) * A(s - i) * A(s - j) * A(s - k) / A(s)
+    return c
+
+
+@pytest.mark.parametrize("R", [1, 2, 5, 9])
+def test_library_tables_against_exact_rationals(R):
+    from fractions import Fraction
+    from mlmc_amd import _lib
+    c = _exact_legendre_products(2 * R)              # products of products need the table of the doubled size
+    t1 = _lib_table(_lib.LEGENDRE, R, False)
+    t2 = _lib_table(_lib.LEGENDRE, R, True)
+    for i in range(R):
+        for j in range(R):
+            row = {k: c[i, j, k] for k in range(abs(i - j), i + j + 1, 2)}
+            for k in range(2 * R - 1):
+                assert t1[k, i, j] == float(row.get(k, Fraction(0))), (i, j, k)
+            sq = {}
+            for a, ca in row.items():
+                for b, cb in row.items():
+                    for k in range(abs(a - b), a + b + 1, 2):
+                        sq[k] = sq.get(k, Fraction(0)) + ca * cb * c[a, b, k]
+            for k in range(4 * R - 3):
+                exact = float(sq.get(k, Fraction(0)))
+                assert abs(t2[k, i, j] - exact) <= 4e-16 * max(exact, 1e-3), (i, j, k, t2[k, i, j], exact)
+                if k not in sq:
+                    assert t2[k, i, j] == 0.0
+
+
+@pytest.mark.parametrize("R", [17, 64])
+def test_library_tables_properties_and_python_twin(R):
+    """Full sizes: the product table is bit for bit the one of mlmc_amd/linearize.py (same recurrences in the same extended
+    precision); both tables are non-negative, symmetric in (i, j), their rows sum to one (phi_k(1) = 1), and the squares' table
+    has zeros at odd k and beyond 2 (i + j)."""
+    from mlmc_amd import linearize
+    t1 = _lib_table(0, R, False)
+    py = linearize.legendre_products(R).reshape(R, R, 2 * R - 1).transpose(2, 0, 1)
+    assert np.array_equal(t1, py)
+    t2 = _lib_table(0, R, True)
+    for t in (t1, t2):
+        assert np.all(t >= 0) and np.array_equal(t, t.transpose(0, 2, 1))
+        assert np.max(np.abs(t.sum(axis=0) - 1.0)) < 5e-15
+    assert not t2[1::2].any()
+    I, J = np.meshgrid(np.arange(R), np.arange(R), indexing="ij")
+    for k in range(4 * R - 3):
+        assert not t2[k][2 * (I + J) < k].any()
+    # squares' table = the product table applied twice (in double: agreement to rounding)
+    big = linearize.legendre_products(2 * R - 1).reshape(2 * R - 1, 2 * R - 1, 4 * R - 3)
+    i, j = R - 1, R // 2
+    v = t1[:, i, j]
+    ref = np.einsum("a,b,abk->k", v, v, big)
+    assert np.max(np.abs(t2[:, i, j] - ref)) < 1e-14
+    # monomials: exponents add
+    m1, m2 = _lib_table(1, 5, False), _lib_table(1, 5, True)
+    assert m1.sum() == 25 and m2.sum() == 25 and m1[3 + 4, 3, 4] == 1.0 and m2[2 * (3 + 4), 3, 4] == 1.0
