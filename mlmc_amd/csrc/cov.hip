@@ -833,10 +833,20 @@ __global__ __launch_bounds__(256, COV_T4_WGS) void k_cov_accum_t4(BasisParams bp
 // workgroup left a 24-component quantity of small chunks waiting on 12 of them).
 __global__ __launch_bounds__(1024) void k_reduce_cov(const double *__restrict__ partials, int nrows, int NT, int NG, int RP,
                                                     int roff, int coff, double *__restrict__ totals, int64_t comp_stride,
-                                                    int mirror) {
+                                                    int mirror, const int64_t *__restrict__ pcounts, int nblocks,
+                                                    int64_t *__restrict__ counts) {
     __shared__ double lds[64][17];
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int width = NG * NT * NT;
+    if (pcounts && blockIdx.x == gridDim.x - 1) {      // one more workgroup: the sample counts of the launch (exact integer sums)
+        if (blockIdx.y == 0 && threadIdx.x < 64) {
+            int64_t a = 0, b = 0;
+            for (int i = threadIdx.x; i < nblocks; i += 64) { a += pcounts[2 * i]; b += pcounts[2 * i + 1]; }
+            for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+            if (threadIdx.x == 0) { counts[0] += a; counts[1] += b; }
+        }
+        return;
+    }
     partials += (int64_t)blockIdx.y * nrows * width;       // blockIdx.y = component: its partial rows, its totals
     totals += (int64_t)blockIdx.y * comp_stride;
     const int col = blockIdx.x * 16 + c;
@@ -857,13 +867,6 @@ __global__ __launch_bounds__(1024) void k_reduce_cov(const double *__restrict__ 
             if (mirror) totals[(int64_t)gi * RP * RP + (int64_t)cc * RP + row] += v;
         }
     }
-}
-
-__global__ void k_reduce_counts2(const int64_t *__restrict__ pcounts, int nblocks, int64_t *__restrict__ counts) {
-    int64_t a = 0, b = 0;
-    for (int i = threadIdx.x; i < nblocks; i += 64) { a += pcounts[2 * i]; b += pcounts[2 * i + 1]; }
-    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-    if (threadIdx.x == 0) { counts[0] += a; counts[1] += b; }
 }
 
 template <int KIND, int T, int MODE, int BI, int BJ>
@@ -960,13 +963,10 @@ int launch_cov_from_values(mlmc_accum *a, int level, int comp, const double *d_v
                 // the generic kernel's tile lists: no symmetric savings inside a block except the SLICED (T <= 2) upper tiles
                 a->mfma_flops += (int64_t)512 * n * (T <= 2 ? (pair ? 2 * T * T + T * (T + 1) / 2 : T * (T + 1)) : (pair ? 3 : 2) * 16);
             }
-            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16)), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, NG,
-                               a->RP, 64 * bi, 64 * bj, totals, (int64_t)0, (symmetric && wide) ? 1 : 0);
+            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16) + (do_count ? 1u : 0u)), dim3(1024), 0, st, a->d_partials,
+                               blocks * n_slices, NT, NG, a->RP, 64 * bi, 64 * bj, totals, (int64_t)0, (symmetric && wide) ? 1 : 0,
+                               do_count ? a->d_pcounts : (const int64_t *)nullptr, blocks, a->d_counts + 2 * (int64_t)level);
             MLMC_HIP_CHECK(hipGetLastError());
-            if (do_count) {
-                hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
-                MLMC_HIP_CHECK(hipGetLastError());
-            }
         }
     return 0;
 }
@@ -1214,13 +1214,10 @@ int launch_cov_accum(mlmc_accum *a, int level, int comp, const double *d_f, cons
                 a->alg_bytes += (int64_t)n * (pair ? 16 : 8) * ncomp;
                 a->mfma_flops += (int64_t)512 * cov_tiles_per_sample(T, bi == bj, pair, gram_mode) * n * ncomp;
             }
-            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16), ncomp), dim3(1024), 0, st, a->d_partials, blocks * n_slices, NT, NG,
-                               a->RP, 64 * bi, 64 * bj, totals, a->int_width, (!pair && bi != bj) ? 1 : 0);
+            hipLaunchKernelGGL(k_reduce_cov, dim3((unsigned)((width + 15) / 16) + (do_count ? 1u : 0u), ncomp), dim3(1024), 0, st, a->d_partials,
+                               blocks * n_slices, NT, NG, a->RP, 64 * bi, 64 * bj, totals, a->int_width, (!pair && bi != bj) ? 1 : 0,
+                               do_count ? a->d_pcounts : (const int64_t *)nullptr, blocks, a->d_counts + 2 * (int64_t)level);
             MLMC_HIP_CHECK(hipGetLastError());
-            if (do_count) {
-                hipLaunchKernelGGL(k_reduce_counts2, dim3(1), dim3(64), 0, st, a->d_pcounts, blocks, a->d_counts + 2 * (int64_t)level);
-                MLMC_HIP_CHECK(hipGetLastError());
-            }
         }
     return 0;
 }
@@ -1256,18 +1253,34 @@ __global__ void k_cov_finalize(const double *__restrict__ totals, const double *
 
 // Mean of the covariance through the product linearisation: out_s[lc][i][j] = sum_k c_ijk (scale_k S_k[lc]), S = level sums of
 // the 2 R - 1 (scaled) moments of the inner accumulator.  The table is k-major: consecutive threads read consecutive entries.
+// A thread owns one (i, j) for up to LIN_LC (level, component) rows: every table entry is read once per LIN_LC rows.  parity_step 2
+// (Legendre): c_ijk = 0 unless k = i + j (mod 2) (products), c2_ijk = 0 for odd k (squares: `squares` != 0) -- the other half of
+// the table is not even read.
+constexpr int LIN_LC = 8;
 __global__ void k_cov_lin_mean(const double *__restrict__ prod, const double *__restrict__ lin_totals, const double *__restrict__ lin_scale,
-                               int R, int K, int64_t lin_width, double *__restrict__ out_s) {
-    extern __shared__ double m_s[];     // [K] true-value sums of this (level, component)
-    const int lc = blockIdx.y;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) m_s[k] = lin_scale[k] * lin_totals[(int64_t)lc * lin_width + k];
+                               int R, int K, int64_t lin_width, double *__restrict__ out_s, int n_lc, int parity_step, int squares) {
+    extern __shared__ double m_s[];     // [LIN_LC][K] true-value sums of these (level, component) rows
+    const int lc0 = blockIdx.y * LIN_LC;
+    for (int q = threadIdx.x; q < LIN_LC * K; q += blockDim.x) {
+        const int l = q / K, k = q % K;
+        m_s[q] = lc0 + l < n_lc ? lin_scale[k] * lin_totals[(int64_t)(lc0 + l) * lin_width + k] : 0.0;
+    }
     __syncthreads();
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int RR = R * R;
     if (idx >= RR) return;
-    double acc = 0.0;
-    for (int k = 0; k < K; ++k) acc = __builtin_fma(prod[(int64_t)k * RR + idx], m_s[k], acc);
-    out_s[(int64_t)lc * RR + idx] += acc;         // (+ the G0 sums of the chunks that kept all three Gram matrices)
+    double acc[LIN_LC];
+#pragma unroll
+    for (int l = 0; l < LIN_LC; ++l) acc[l] = 0.0;
+    const int k0 = (parity_step == 2 && !squares) ? ((idx / R + idx % R) & 1) : 0;
+    for (int k = k0; k < K; k += parity_step) {
+        const double c = prod[(int64_t)k * RR + idx];
+#pragma unroll
+        for (int l = 0; l < LIN_LC; ++l) acc[l] = __builtin_fma(c, m_s[l * K + k], acc[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < LIN_LC; ++l)
+        if (lc0 + l < n_lc) out_s[(int64_t)(lc0 + l) * RR + idx] += acc[l];     // (+ the sums of the chunks that went the direct way)
 }
 
 int launch_cov_finalize(mlmc_accum *a) {
@@ -1278,6 +1291,8 @@ int launch_cov_finalize(mlmc_accum *a) {
     if (lin0) {
         if (int rc = flush_moments(a->lin0)) return rc;
     }
+    const dim3 lin_grid((a->R * a->R + 255) / 256, (a->n_levels * a->n_comp + LIN_LC - 1) / LIN_LC);
+    const int pstep = a->basis->p.kind == MLMC_LEGENDRE ? 2 : 1;
     const int n_lc = a->n_levels * a->n_comp;
     const bool vals = a->cov_from_values;              // TransformedMoments / more than 128 moments: accumulated from true values
     const int R = vals ? a->Rout : a->R;
@@ -1289,15 +1304,15 @@ int launch_cov_finalize(mlmc_accum *a) {
     if (lin0) {
         // level-0 chunks that went without a matrix pass: sum f_i f_j from the first 2 R - 1 extended sums, sum (f_i f_j)^2 from all
         // 4 R - 3 (at level 0 the finalize formula 1/4 (G1 + G1^T + 2 G2) is this very sum: both kinds of chunk add up)
-        hipLaunchKernelGGL(k_cov_lin_mean, dim3((R * R + 255) / 256, n_lc), dim3(256), sizeof(double) * a->lin_K, rt().stream,
-                           a->d_lin_prod, a->lin0->d_totals, a->lin0_basis->d_scale, R, a->lin_K, a->lin0->int_width, a->d_out_s);
-        hipLaunchKernelGGL(k_cov_lin_mean, dim3((R * R + 255) / 256, n_lc), dim3(256), sizeof(double) * a->lin0_K, rt().stream,
-                           a->d_lin0_prod, a->lin0->d_totals, a->lin0_basis->d_scale, R, a->lin0_K, a->lin0->int_width, a->d_out_sp);
+        hipLaunchKernelGGL(k_cov_lin_mean, lin_grid, dim3(256), sizeof(double) * LIN_LC * a->lin_K, rt().stream,
+                           a->d_lin_prod, a->lin0->d_totals, a->lin0_basis->d_scale, R, a->lin_K, a->lin0->int_width, a->d_out_s, n_lc, pstep, 0);
+        hipLaunchKernelGGL(k_cov_lin_mean, lin_grid, dim3(256), sizeof(double) * LIN_LC * a->lin0_K, rt().stream,
+                           a->d_lin0_prod, a->lin0->d_totals, a->lin0_basis->d_scale, R, a->lin0_K, a->lin0->int_width, a->d_out_sp, n_lc, pstep, 1);
         MLMC_HIP_CHECK(hipGetLastError());
     }
     if (a->lin && a->lin_used) {       // chunks without G0 (gram_mode 3): their share of the means comes from the extended moments
-        hipLaunchKernelGGL(k_cov_lin_mean, dim3((R * R + 255) / 256, n_lc), dim3(256), sizeof(double) * a->lin_K, rt().stream,
-                           a->d_lin_prod, a->lin->d_totals, a->lin_basis->d_scale, R, a->lin_K, a->lin->int_width, a->d_out_s);
+        hipLaunchKernelGGL(k_cov_lin_mean, lin_grid, dim3(256), sizeof(double) * LIN_LC * a->lin_K, rt().stream,
+                           a->d_lin_prod, a->lin->d_totals, a->lin_basis->d_scale, R, a->lin_K, a->lin->int_width, a->d_out_s, n_lc, pstep, 0);
         MLMC_HIP_CHECK(hipGetLastError());
     }
     return 0;
