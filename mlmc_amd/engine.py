@@ -247,7 +247,11 @@ def level_stats(n, s, sp):
     nf = n.astype(np.float64)[:, None]
     s = np.asarray(s)
     if n.min() > 1:                                   # the usual case: no division by zero to silence, no level to patch
-        return s / nf, (sp - (s * s / nf)) / (nf - 1.0)
+        l_vars = s * s                                # (sp - s * s / n) / (n - 1), same operations in the same order, one temporary
+        l_vars /= nf
+        np.subtract(sp, l_vars, out=l_vars)
+        l_vars /= nf - 1.0
+        return s / nf, l_vars
     with np.errstate(all="ignore"):
         l_means = s / nf
         l_vars = (sp - (s * s / nf)) / (nf - 1.0)
