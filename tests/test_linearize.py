@@ -331,3 +331,19 @@ def test_library_tables_properties_and_python_twin(R):
     # monomials: exponents add
     m1, m2 = _lib_table(1, 5, False), _lib_table(1, 5, True)
     assert m1.sum() == 25 and m2.sum() == 25 and m1[3 + 4, 3, 4] == 1.0 and m2[2 * (3 + 4), 3, 4] == 1.0
+
+
+def test_library_table_argument_checks():
+    from mlmc_amd import _lib
+    lib = _lib.load()
+    out = np.empty(16)
+    for args in ((2, 4, 0, _lib.ptr(out), 16),          # Fourier: no table here
+                 (0, 0, 0, _lib.ptr(out), 16),          # size out of range
+                 (0, 129, 0, _lib.ptr(out), 16),
+                 (0, 65, 1, _lib.ptr(out), 16),         # squares: at most 64 moments
+                 (0, 3, 0, _lib.ptr(out), 16),          # needs 5 * 9 = 45 doubles
+                 (0, 2, 0, None, 16)):
+        assert lib.mlmc_linearization_table(*args) != 0
+        assert lib.mlmc_last_error().decode() != ""
+    assert lib.mlmc_linearization_table(0, 2, 0, _lib.ptr(out), 16) == 0       # 3 * 4 = 12 doubles fit
+    assert np.array_equal(out[:12].reshape(3, 2, 2)[:, 1, 1], [1.0 / 3.0, 0.0, 2.0 / 3.0])   # P_1^2 = 1/3 P_0 + 2/3 P_2
