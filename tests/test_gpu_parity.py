@@ -169,10 +169,16 @@ def test_estimate_moments_vector_quantity(hip, g2):
     assert close(mean, g2[key + "_mean"].ravel(), 1.0, TOL) and close(var, g2[key + "_var"].ravel(), None, TOL)
 
 
+@pytest.mark.parametrize("lin", ["default", "forced"])
 @pytest.mark.parametrize("tag", ["L3", "L3nan", "L1"])
-def test_estimate_covariance_golden(hip, g2, tag):
+def test_estimate_covariance_golden(hip, g2, tag, lin, monkeypatch):
+    """Covariance estimates against the REFERENCE's own outputs (G3, generated by importing the reference).  `forced`: every
+    chunk takes the library's linearised route (mean from 2 R - 1 moments, level 0 from 4 R - 3; R = 24 and 64 here) -- at the
+    fixtures' sizes the default keeps all three Gram matrices on the matrix cores."""
     from mlmc_amd import Legendre
     from mlmc_amd.engine import LevelAccumulator
+    if lin == "forced":
+        monkeypatch.setenv("MLMC_HIP_LINEARIZE_MIN_N", "0")
     g3 = np.load(os.path.join(GOLDEN, "G3_cov.npz"))
     dom = tuple(g2["domain"])
     N, steps, nan_every = g2[f"{tag}_N"], g2[f"{tag}_steps"], int(g2[f"{tag}_nan_every"])
