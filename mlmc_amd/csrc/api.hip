@@ -227,6 +227,16 @@ bool square_product_table(int kind, int R, std::vector<double> &out) {
                 out[(size_t)k * RR + (size_t)j * R + i] = c;
             }
         }
+    // (P_0 P_j)^2 = P_j^2: these rows are the product table's own (Adams' formula) -- in particular c2_00k = delta_k0 EXACTLY,
+    // which the exact sample counts in the P_0 P_0 entries (and vars[0] == 0) rest on, whatever the last bit of the quadrature
+    std::vector<double> t1;
+    product_table(kind, R, t1);
+    for (int j = 0; j < R; ++j)
+        for (int k = 0; k < K; ++k) {
+            const double c = k < 2 * R - 1 ? t1[(size_t)k * RR + (size_t)j * R + j] : 0.0;
+            out[(size_t)k * RR + (size_t)j] = c;
+            out[(size_t)k * RR + (size_t)j * R] = c;
+        }
     return true;
 }
 

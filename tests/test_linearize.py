@@ -319,6 +319,10 @@ def test_library_tables_properties_and_python_twin(R):
         assert np.all(t >= 0) and np.array_equal(t, t.transpose(0, 2, 1))
         assert np.max(np.abs(t.sum(axis=0) - 1.0)) < 5e-15
     assert not t2[1::2].any()
+    # (P_0 P_j)^2 = P_j^2: rows with i = 0 are the product table's, exactly -- c2_00k = delta_k0 carries the exact counts
+    assert t2[0, 0, 0] == 1.0 and not t2[1:, 0, 0].any()
+    for j in range(R):
+        assert np.array_equal(t2[:2 * R - 1, 0, j], t1[:, j, j]) and not t2[2 * R - 1:, 0, j].any()
     I, J = np.meshgrid(np.arange(R), np.arange(R), indexing="ij")
     for k in range(4 * R - 3):
         assert not t2[k][2 * (I + J) < k].any()
