@@ -444,6 +444,77 @@ int mlmc_basis_eval(const mlmc_basis *b, const double *x, int64_t n, int32_t siz
     return rc;
 }
 
+// The coefficient tables of the linearisations live on the device once per (family, size) for the life of the process (4 MB +
+// 8 MB at R = 64): accumulators share them.
+struct LinTables {
+    double *d_prod = nullptr, *d_prod2 = nullptr;
+};
+static int lin_tables(int kind, int R, bool squares, LinTables **out) {
+    static std::map<std::pair<int, int>, LinTables> cache;
+    LinTables &t = cache[std::make_pair(kind, R)];
+    if (!t.d_prod) {
+        std::vector<double> h;
+        product_table(kind, R, h);
+        MLMC_HIP_CHECK(hipMalloc(&t.d_prod, sizeof(double) * h.size()));
+        MLMC_HIP_CHECK(hipMemcpy(t.d_prod, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    }
+    if (squares && !t.d_prod2) {
+        std::vector<double> h;                  // ~0.2 s of host time at R = 64
+        square_product_table(kind, R, h);
+        MLMC_HIP_CHECK(hipMalloc(&t.d_prod2, sizeof(double) * h.size()));
+        MLMC_HIP_CHECK(hipMemcpy(t.d_prod2, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    }
+    *out = &t;
+    return 0;
+}
+
+// Inner accumulators of a covariance accumulator that takes (part of) its sums from level sums of moments; called with the
+// first chunk that is large enough.
+static int ensure_lin(mlmc_accum *a) {
+    if (a->lin) return 0;
+    const mlmc_basis *b = a->basis;
+    LinTables *t = nullptr;
+    if (int rc = lin_tables(b->p.kind, a->R, a->lin0_eligible, &t)) return rc;
+    mlmc_basis_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.kind = b->p.kind;
+    d.size = 2 * a->R - 1;
+    d.shift = b->p.shift; d.scale = b->p.scale; d.ref0 = b->p.ref0; d.ref1 = b->p.ref1;
+    d.is_log = b->p.is_log; d.is_clip = b->p.is_clip;
+    d.x_lo = b->p.x_lo; d.x_hi = b->p.x_hi;              // the very thresholds of the caller's basis: the same samples are kept
+    int rc = mlmc_basis_create(&d, &a->lin_basis);
+    if (!rc) rc = mlmc_accum_create(a->lin_basis, a->n_levels, MLMC_MODE_MOMENTS | MLMC_MODE_MEAN_ONLY, a->n_comp, &a->lin);
+    if (!rc) {
+        a->lin_basis->p.x_lo = b->p.x_lo;                // (a desc with x_lo == x_hi == 0 would have been bisected anew)
+        a->lin_basis->p.x_hi = b->p.x_hi;
+        a->lin->host_outputs = false;                    // its totals are read on the device (launch_cov_finalize)
+        a->lin_K = d.size;
+        a->d_lin_prod = t->d_prod;
+    }
+    if (!rc && a->lin0_eligible) {
+        d.size = 4 * a->R - 3;
+        rc = mlmc_basis_create(&d, &a->lin0_basis);
+        if (!rc) rc = mlmc_accum_create(a->lin0_basis, a->n_levels, MLMC_MODE_MOMENTS | MLMC_MODE_MEAN_ONLY, a->n_comp, &a->lin0);
+        if (!rc) {
+            a->lin0_basis->p.x_lo = b->p.x_lo;
+            a->lin0_basis->p.x_hi = b->p.x_hi;
+            a->lin0->host_outputs = false;
+            a->lin0_K = d.size;
+            a->d_lin0_prod = t->d_prod2;
+        }
+    }
+    if (rc) {            // no half-built state: the accumulator goes on with all three Gram matrices
+        if (a->lin) mlmc_accum_destroy(a->lin);
+        if (a->lin_basis) mlmc_basis_destroy(a->lin_basis);
+        if (a->lin0) mlmc_accum_destroy(a->lin0);
+        if (a->lin0_basis) mlmc_basis_destroy(a->lin0_basis);
+        a->lin = a->lin0 = nullptr;
+        a->lin_basis = a->lin0_basis = nullptr;
+        a->lin_eligible = a->lin0_eligible = false;
+    }
+    return rc;
+}
+
 // ---- accumulators ---------------------------------------------------------------------------
 int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32_t n_comp, mlmc_accum **out) {
     MLMC_API_GUARD;
@@ -503,57 +574,19 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     a->d_out_nd = (double *)(a->d_out_n + 2 * (size_t)n_levels);
     a->d_out_s = a->d_out_nd + 2 * (size_t)n_levels;
     a->d_out_sp = a->d_out_s + (size_t)n_levels * a->K;
-    // covariance WITH variances of 17..128 plain polynomial moments: mean through the product linearisation (mlmc_hip.h)
+    // covariance WITH variances of 17..128 plain polynomial moments: mean through the product linearisation (mlmc_hip.h) -- the
+    // inner accumulators and the coefficient tables come into being with the first chunk large enough to use them (ensure_lin):
+    // an accumulator that only ever sees small chunks costs what it cost before
     if (mode == MLMC_MODE_COV && !mean_only && !a->cov_from_values && b->out_size == 0 && b->p.size > lin_min_size() && b->p.size <= 128 &&
         (b->p.kind == MLMC_LEGENDRE || b->p.kind == MLMC_MONOMIAL) && linearize_enabled()) {
-        std::vector<double> table;
-        product_table(b->p.kind, a->R, table);
-        mlmc_basis_desc d;
-        std::memset(&d, 0, sizeof(d));
-        d.kind = b->p.kind;
-        d.size = 2 * a->R - 1;
-        d.shift = b->p.shift; d.scale = b->p.scale; d.ref0 = b->p.ref0; d.ref1 = b->p.ref1;
-        d.is_log = b->p.is_log; d.is_clip = b->p.is_clip;
-        d.x_lo = b->p.x_lo; d.x_hi = b->p.x_hi;              // the very thresholds of the caller's basis: the same samples are kept
-        int rc = mlmc_basis_create(&d, &a->lin_basis);
-        if (!rc) rc = mlmc_accum_create(a->lin_basis, n_levels, MLMC_MODE_MOMENTS | MLMC_MODE_MEAN_ONLY, n_comp, &a->lin);
-        if (!rc) {
-            a->lin_basis->p.x_lo = b->p.x_lo;                // (a desc with x_lo == x_hi == 0 would have been bisected anew)
-            a->lin_basis->p.x_hi = b->p.x_hi;
-            a->lin->host_outputs = false;                    // its totals are read on the device (launch_cov_finalize)
-            a->lin_K = d.size;
-            // break-even of the auxiliary pass (three more launches per estimate, ~30 us) against the matrix time it saves
-            // (~80 ps per sample at 33..64 moments, ~9 ps at 17..32): measured with tools/kbench.py --n
-            const char *min_n = std::getenv("MLMC_HIP_LINEARIZE_MIN_N");
-            a->lin_min_n = min_n ? std::atoll(min_n) : (a->R > 32 ? 100000 : 1500000);
-            hipError_t e = hipMalloc(&a->d_lin_prod, sizeof(double) * table.size());
-            if (e == hipSuccess) e = hipMemcpy(a->d_lin_prod, table.data(), sizeof(double) * table.size(), hipMemcpyHostToDevice);
-            if (e != hipSuccess) rc = fail(std::string("mlmc_accum_create: ") + hipGetErrorString(e));
-        }
+        a->lin_eligible = true;
+        // break-even of the auxiliary pass (three more launches per estimate, ~30 us) against the matrix time it saves
+        // (~80 ps per sample at 33..64 moments, ~9 ps at 17..32): measured with tools/kbench.py --n
+        const char *min_n = std::getenv("MLMC_HIP_LINEARIZE_MIN_N");
+        a->lin_min_n = min_n ? std::atoll(min_n) : (a->R > 32 ? 100000 : 1500000);
         // level 0 without the matrix cores (<= 64 moments: the 4 R - 3 extended terms fit the two windows of the mean-only kernel)
         const char *lin0_env = std::getenv("MLMC_HIP_LINEARIZE_LEVEL0");
-        if (!rc && a->R <= 64 && !(lin0_env && lin0_env[0] == '0')) {
-            // the table costs ~1 s of host time at R = 64: built once per (family, size)
-            static std::map<std::pair<int, int>, std::vector<double>> cache;
-            std::vector<double> &t2 = cache[std::make_pair((int)b->p.kind, a->R)];
-            if (t2.empty()) square_product_table(b->p.kind, a->R, t2);
-            d.size = 4 * a->R - 3;
-            rc = mlmc_basis_create(&d, &a->lin0_basis);
-            if (!rc) rc = mlmc_accum_create(a->lin0_basis, n_levels, MLMC_MODE_MOMENTS | MLMC_MODE_MEAN_ONLY, n_comp, &a->lin0);
-            if (!rc) {
-                a->lin0_basis->p.x_lo = b->p.x_lo;
-                a->lin0_basis->p.x_hi = b->p.x_hi;
-                a->lin0->host_outputs = false;
-                a->lin0_K = d.size;
-                hipError_t e = hipMalloc(&a->d_lin0_prod, sizeof(double) * t2.size());
-                if (e == hipSuccess) e = hipMemcpy(a->d_lin0_prod, t2.data(), sizeof(double) * t2.size(), hipMemcpyHostToDevice);
-                if (e != hipSuccess) rc = fail(std::string("mlmc_accum_create: ") + hipGetErrorString(e));
-            }
-        }
-        if (rc) {
-            mlmc_accum_destroy(a);
-            return rc;
-        }
+        a->lin0_eligible = a->R <= 64 && !(lin0_env && lin0_env[0] == '0');
     }
     *out = a;
     return mlmc_accum_reset(a);
@@ -581,9 +614,7 @@ void mlmc_accum_destroy(mlmc_accum *a) {
     if (a->lin) mlmc_accum_destroy(a->lin);
     if (a->lin_basis) mlmc_basis_destroy(a->lin_basis);
     if (a->lin0) mlmc_accum_destroy(a->lin0);
-    if (a->lin0_basis) mlmc_basis_destroy(a->lin0_basis);
-    if (a->d_lin0_prod) (void)hipFree(a->d_lin0_prod);
-    if (a->d_lin_prod) (void)hipFree(a->d_lin_prod);
+    if (a->lin0_basis) mlmc_basis_destroy(a->lin0_basis);         // (the coefficient tables are shared: lin_tables)
     void *ptrs[] = {a->d_state, a->d_partials, a->d_pcounts, a->d_stage_f, a->d_stage_c, a->d_mask, a->d_out, a->d_vals_f, a->d_vals_c, a->d_vals_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -718,6 +749,8 @@ int mlmc_accum_push(mlmc_accum *a, int32_t level, const double *fine, const doub
             // all components of a vector quantity in one launch (grid.y = component; they share the mask)
             // level 0 (one value per sample) of <= 64 moments: mean AND second moments from the level sums of 4 R - 3 moments --
             // no matrix pass; the moments kernel does the counting
+            if (a->lin_eligible && !a->lin && n >= a->lin_min_n)
+                if (int rcl = ensure_lin(a)) return rcl;
             const bool use_lin0 = a->lin0 && !d_c && n >= a->lin_min_n;
             if (use_lin0) {
                 a->lin0_used = true;

@@ -129,9 +129,10 @@ struct mlmc_accum {
     // COV with variances of 17..128 plain Legendre / monomial moments: the MEAN of the covariance comes from the level sums of
     // the 2 R - 1 moments of the product linearisation (phi_i phi_j = sum_k c_ijk phi_k) -- an inner mean-only MOMENTS
     // accumulator over the same chunks -- and the matrix cores compute G1, G2 only (26 instead of 42 tiles per pair)
+    bool lin_eligible = false, lin0_eligible = false;   // decided at create; the inner accumulators appear with the first large chunk
     mlmc_accum *lin = nullptr;
     mlmc_basis *lin_basis = nullptr;      // the family's member of size lin_K = 2 R - 1
-    double *d_lin_prod = nullptr;         // [lin_K][R * R]: c_ijk, k-major
+    double *d_lin_prod = nullptr;         // [lin_K][R * R]: c_ijk, k-major (shared per family and size, not owned)
     int lin_K = 0;
     // ... and at LEVEL 0 (one value per sample) the variance linearises as well: (phi_i phi_j)^2 = sum_k c2_ijk phi_k, k < 4 R - 3, so a
     // large level-0 chunk of <= 64 moments needs no matrix pass at all -- a second inner accumulator over the size-(4 R - 3) member
