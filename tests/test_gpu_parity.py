@@ -1208,6 +1208,20 @@ def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
         # chunks of 1767 | 3534, 833 | 1667, 592 | 1185 samples: direct and linearised contributions in one level
         n, n_rm, s, sp = both(cls(R, dom), levels, device=True, split=True, min_n="1500" if R <= 64 else "300")
         _check_against(n, n_rm, s, sp, ref)
+    # every level in two chunks of 400 samples and the rest, threshold 1000: the small chunk keeps its Gram matrices (and is counted
+    # by the covariance kernel), the large one goes through the extended moments (level 0: counted by the moments kernel) -- sums
+    # and counts add up
+    if R <= 64:
+        monkeypatch.setenv("MLMC_HIP_LINEARIZE_MIN_N", "1000")
+        acc = LevelAccumulator(Legendre(R, dom), len(levels), LevelAccumulator.COV)
+        for l, (f, c) in enumerate(levels):
+            for lo, hi in ((0, 400), (400, f.shape[-1])):
+                acc.push(l, np.ascontiguousarray(f[0, lo:hi]), None if c is None else np.ascontiguousarray(c[0, lo:hi]))
+        n, n_rm, s, sp = acc.finalize()
+        acc.close()
+        monkeypatch.delenv("MLMC_HIP_LINEARIZE_MIN_N")
+        b = onp.Basis(onp.LEGENDRE, R, dom)
+        _check_against(n, n_rm, s, sp, onp.estimate_mean(to_chunks(levels), lambda x: onp.covariance_rows(b, x)))
     # two components: a sample is dropped when any component is masked
     lv2 = level_arrays([2800, 1100] if R <= 64 else [700, 300], [0.3, 0.02], 2, 6)
     b = onp.Basis(onp.LEGENDRE, R, dom)
