@@ -29,6 +29,11 @@ def extended_size(fn):
     if R > MAX_R:
         return None
     if type(fn) in (Legendre, Monomial):
+        # Without clipping to the domain (safe_eval=False) a value outside it makes the HIGH extended terms overflow (P_k grows
+        # like (x + sqrt(x^2 - 1))^k beyond 1) while the low products it is not needed for stay finite -- and 0 * inf in the
+        # contraction would turn those into NaN.  The direct form touches, per entry, only its own two factors.
+        if not getattr(fn, "_is_clip", True):
+            return None
         return 2 * R - 1
     if type(fn) is Fourier:
         return 4 * (R // 2) + 1

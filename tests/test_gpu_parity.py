@@ -1241,3 +1241,26 @@ def test_covariance_mean_through_the_product_linearisation(hip, R, monkeypatch):
     ref = onp.estimate_mean(to_chunks(lvl), lambda v: onp.covariance_rows(bl, v))
     n, n_rm, s, sp = both(Legendre(R, ldom, log=True), lvl)
     _check_against(n, n_rm, s, sp, ref)
+
+
+def test_unclipped_moments_keep_the_direct_covariance(hip, monkeypatch):
+    """safe_eval=False: values outside the domain are not masked, the high extended terms of a linearisation would overflow for
+    them (and 0 * inf would poison the entries that do not need them) -- such bases keep all three Gram matrices on the matrix
+    cores, whatever the chunk size, and the mean-only route of estimate_mean is the direct one too."""
+    from mlmc_amd import Legendre, linearize
+    from mlmc_amd.engine import LevelAccumulator
+    dom = (-3.7190164854556804, 3.7190164854556804)
+    levels = level_arrays([4001, 2500], [0.5, 0.07], 1, 0)
+    levels[0][0][0, 17] = 40.0                      # far outside: P_k(t) ~ 10^(1.3 k) there
+    out = []
+    for lin in ("1", "0"):
+        monkeypatch.setenv("MLMC_HIP_LINEARIZE", lin)
+        monkeypatch.setenv("MLMC_HIP_LINEARIZE_MIN_N", "0")
+        fn = Legendre(24, dom, safe_eval=False)
+        assert linearize.extended_size(fn) is None
+        out.append(_run_accum(fn, levels, mode=LevelAccumulator.COV))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b, equal_nan=True)
+    s = out[0][2].reshape(2, 24, 24)
+    assert np.all(np.isfinite(s[0, :4, :4]))          # the low products of the outlier are ordinary numbers
+    assert linearize.extended_size(Legendre(24, dom)) == 47
