@@ -578,7 +578,9 @@ int mlmc_accum_create(const mlmc_basis *b, int32_t n_levels, int32_t mode, int32
     // inner accumulators and the coefficient tables come into being with the first chunk large enough to use them (ensure_lin):
     // an accumulator that only ever sees small chunks costs what it cost before
     if (mode == MLMC_MODE_COV && !mean_only && !a->cov_from_values && b->out_size == 0 && b->p.size > lin_min_size() && b->p.size <= 128 &&
-        (b->p.kind == MLMC_LEGENDRE || b->p.kind == MLMC_MONOMIAL) && b->p.is_clip && linearize_enabled()) {
+        (b->p.kind == MLMC_LEGENDRE || b->p.kind == MLMC_MONOMIAL) && b->p.is_clip &&
+        std::fabs(b->p.ref0) <= 1.0 && std::fabs(b->p.ref1) <= 1.0 &&          // (monomials on a wider reference domain: t^(4 R - 4) may overflow)
+        linearize_enabled()) {
         // (is_clip: without clipping to the domain a value outside it makes the HIGH extended terms overflow while the low products it
         // is not needed for stay finite, and 0 * inf in the contraction would turn those into NaN; the direct form touches, per
         // entry, only its own factors)

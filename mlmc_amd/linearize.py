@@ -34,6 +34,8 @@ def extended_size(fn):
         # contraction would turn those into NaN.  The direct form touches, per entry, only its own two factors.
         if not getattr(fn, "_is_clip", True):
             return None
+        if max(abs(float(fn.ref_domain[0])), abs(float(fn.ref_domain[1]))) > 1.0:      # monomials on a wider reference domain
+            return None
         return 2 * R - 1
     if type(fn) is Fourier:
         return 4 * (R // 2) + 1

@@ -351,3 +351,13 @@ def test_library_table_argument_checks():
         assert lib.mlmc_last_error().decode() != ""
     assert lib.mlmc_linearization_table(0, 2, 0, _lib.ptr(out), 16) == 0       # 3 * 4 = 12 doubles fit
     assert np.array_equal(out[:12].reshape(3, 2, 2)[:, 1, 1], [1.0 / 3.0, 0.0, 2.0 / 3.0])   # P_1^2 = 1/3 P_0 + 2/3 P_2
+
+
+def test_no_linearisation_where_extended_terms_could_overflow():
+    """Unclipped bases and monomials on a reference domain beyond [-1, 1]: the high extended terms are not bounded by one there."""
+    from mlmc_amd import Legendre, Monomial, linearize
+    assert linearize.extended_size(Legendre(10, (-2.0, 2.0))) == 19
+    assert linearize.extended_size(Legendre(10, (-2.0, 2.0), safe_eval=False)) is None
+    assert linearize.extended_size(Monomial(10, (0.0, 5.0))) == 19
+    assert linearize.extended_size(Monomial(10, (0.0, 5.0), ref_domain=(0, 3))) is None
+    assert linearize.extended_size(Monomial(10, (0.0, 5.0), safe_eval=False)) is None
